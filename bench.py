@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/sec of the VAQ ADC search path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+
+One "step" = one pass of the hot path (project -> LUT build -> code scan with
+top-k -> merge [-> all-gather + merge across GPUs]) over one batch of nq
+synthetic queries that are already resident in HBM, results left in HBM.
+
+Workloads (BASELINE.json configs):
+  c2  SIFT-1M-shaped, d=128, 8 subspaces x 256 centroids, 10k queries, k=100
+      (the configuration the metric is quoted on; default)
+  c3  same data, non-uniform bits {12,10,9,8,8,7,6,4}
+  c5  1B x 128, 16 x 256 (uniform-random codes unless --encode; --rows scales it)
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the code rows
+are sharded contiguously across ranks, every rank answers all
+queries on its shard, and one RCCL all-gather of the per-shard top-k plus a
+merge kernel finishes the step: total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--rows", type=int, default=0, help="override database rows (total)")
+    ap.add_argument("--nq", type=int, default=0, help="override queries per step")
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--qb", type=int, default=0, help="queries per pass (0 = library default)")
+    ap.add_argument("--slices", type=int, default=0)
+    ap.add_argument("--kcap", type=int, default=0)
+    ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
+    ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vaq_amd
+    from vaq_amd import build, harness
+    from vaq_amd.index import merge_topk_device
+    build.build_lib()
+
+    D, k = 128, args.k
+    if args.workload == "c2":
+        bits, N, nq, name = [8] * 8, 1_000_000, 10_000, "sift1m-shaped d128 m8x256 nq10k k100"
+    elif args.workload == "c3":
+        bits, N, nq, name = list(harness.C3_BITS), 1_000_000, 10_000, "sift1m-shaped d128 bits{12,10,9,8,8,7,6,4} nq10k k100"
+    else:
+        bits, N, nq, name = [8] * 16, 1_000_000_000, 256, "synthetic 1Bx128 m16x256 k100"
+    if args.rows:
+        N = args.rows
+    if args.nq:
+        nq = args.nq
+    M = len(bits)
+
+    # ---------------------------------------------------------------- setup --
+    t_setup = time.time()
+    shard = (N + world - 1) // world
+    lo, hi = min(N, rank * shard), min(N, (rank + 1) * shard)
+    n_local = hi - lo
+    GEN = 1 << 20  # rows per generated chunk; chunk c is the same on every rank layout
+
+    def base_chunk(c):
+        m = min(GEN, N - c * GEN)
+        return harness.sift_like(m, D, stream=1000 + c, device=dev)
+
+    real_codes = args.workload != "c5" or args.encode
+    # train on the first chunk (every rank derives identical state; rank 0's is broadcast)
+    train = base_chunk(0)[: min(N, 262144)]
+    eig = harness.pca_eigenvectors(train).to(dev)
+    if world > 1:
+        dist.broadcast(eig, 0)
+    tp = train @ eig
+    cents = harness.train_codebooks(tp, bits, iters=15 if args.workload != "c5" else 8)
+    if world > 1:
+        for s in range(M):
+            t = torch.from_numpy(cents[s]).to(dev)
+            dist.broadcast(t, 0)
+            cents[s] = t.cpu().numpy()
+    del tp
+
+    v = vaq_amd.VaqHip(device=local_rank)
+    v.parseMethodString("VAQ%dm%dmin%dmax%dvar1,HEAP" % (sum(bits), M, min(bits), max(bits)))
+    v.mBitsAlloc = bits
+    v.mCentroidsPerSubs = cents
+    v.mEigenVectors = eig.cpu().numpy()
+    v.id_base = lo
+
+    codes = torch.empty((n_local, M), dtype=torch.int16, device=dev)
+    if real_codes:
+        c0, c1 = lo // GEN, (hi + GEN - 1) // GEN if hi > lo else lo // GEN
+        for c in range(c0, c1):
+            X = base_chunk(c)
+            a, b = max(lo, c * GEN), min(hi, (c + 1) * GEN)
+            xs = X[a - c * GEN: b - c * GEN]
+            codes[a - lo: b - lo] = harness.encode_torch(xs @ eig, cents)
+            del X, xs
+    else:
+        g = torch.Generator(device=dev).manual_seed(harness.SEED + rank)
+        step_rows = 1 << 24
+        for r in range(0, n_local, step_rows):
+            m = min(step_rows, n_local - r)
+            codes[r: r + m] = torch.randint(0, 256, (m, M), generator=g, device=dev, dtype=torch.int16)
+    v.mCodebook = codes
+    v._ensure_codes()
+    host_codes = None
+    if rank == 0 and not args.no_cpu:
+        n_cpu_rows = min(n_local, 1_000_000 if args.workload != "c5" else 4_000_000)
+        host_codes = codes[:n_cpu_rows].cpu().numpy().view(np.uint16)
+    del codes
+    v.mCodebook = None  # packed copy lives in the index; keep _codes_sig
+    torch.cuda.empty_cache()
+
+    queries = harness.sift_like(nq, D, stream=7, device=dev)
+    if args.qb:
+        v.set_option("queries_per_pass", args.qb)
+    if args.slices:
+        v.set_option("slices", args.slices)
+    if args.kcap:
+        v.set_option("candidate_capacity", args.kcap)
+    info = v.info()
+
+    def run_step():
+        l, d = v.search_device(queries, k)
+        if world > 1:
+            gl = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
+            gd = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(gl, l)
+            dist.all_gather_into_tensor(gd, d)
+            l, d = merge_topk_device(gd, gl, k)
+        return l, d
+
+    log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")
+
+    # ---------------------------------------------------------------- timed --
+    for _ in range(args.warmup):
+        run_step()
+    torch.cuda.synchronize()
+    v.set_option("timing", 1)
+    v.last_timing()  # reset the event ring
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        labels, dists_ = run_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = v.last_timing()  # mean per-kernel device time over exactly these K steps (HIP events
+    #                       recorded on the launch stream by the library)
+    v.set_option("timing", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    qps = nq * args.steps / elapsed
+
+    # ------------------------------------------------------------- roofline --
+    # unit = one database row scanned in one pass; bytes = ceil(sum bits / 8);
+    # one launch scans n_local rows in `passes` = ceil(nq / Qb) passes.
+    algo_bytes = float(n_local) * info["algo_code_bytes"] * tm["passes"]
+    achieved = algo_bytes / (tm["scan_ms"] * 1e-3) / 1e9 if tm["scan_ms"] > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "kernel": "scan_%s_kernel" % ("bytes" if info["layout"] == 0 else "bits"),
+        "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
+        "queries_per_pass": tm["queries_per_pass"], "passes": tm["passes"],
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "effective_per_query_GBps": round(float(n_local) * info["algo_code_bytes"] * nq /
+                                          (tm["scan_ms"] * 1e-3) / 1e9, 1) if tm["scan_ms"] > 0 else 0.0,
+        "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
+                             "merge": round(tm["merge_ms"], 4)},
+        "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
+    }
+
+    # --------------------------------------------------------------- recall --
+    recall = None
+    if not args.no_recall and real_codes and N <= 4_000_000 and rank == 0:
+        nq_r = min(nq, 1000)
+        Xq = queries[:nq_r]
+        nchunks = (N + GEN - 1) // GEN
+        gt = harness.brute_force_topk(Xq, ((c * GEN, base_chunk(c)) for c in range(nchunks)), k)
+        recall = {
+            "recall_at_100": round(harness.avg_recall(labels[:nq_r].cpu().numpy(), gt.cpu().numpy()), 4),
+            "recall_1nn_in_100": round(harness.recall_at_r(labels[:nq_r].cpu().numpy(), gt.cpu().numpy()), 4),
+            "queries": nq_r, "ground_truth": "exact L2 brute force (torch) on the same synthetic base",
+        }
+
+    # --------------------------------------------------------- cpu baseline --
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import pyoracle as po
+        po.build(ref=False)
+        threads = max(1, min(po.max_threads(), os.cpu_count() or 1))
+        qh = queries.cpu().numpy()
+        eig_h = v.mEigenVectors
+        n_rows_cpu = host_codes.shape[0]
+        # calibrate on `threads` queries, then size the sample for ~cpu_seconds
+        t1 = time.perf_counter()
+        po.search(qh[:threads], cents, host_codes, k, eig=eig_h, nthreads=threads)
+        per_round = max(1e-3, time.perf_counter() - t1)
+        n_cpu = int(min(nq, max(threads, threads * (args.cpu_seconds / per_round))))
+        t1 = time.perf_counter()
+        cl, cd = po.search(qh[:n_cpu], cents, host_codes, k, eig=eig_h, nthreads=threads)
+        dt = time.perf_counter() - t1
+        scale = n_rows_cpu / float(N)  # rows scanned per query relative to the full job
+        cpu_qps = n_cpu / dt * scale
+        # single thread = the reference's execution model (VAQ.cpp:786)
+        n1 = max(1, min(n_cpu, int(3.0 / (per_round)) + 1))
+        t1 = time.perf_counter()
+        po.search(qh[:n1], cents, host_codes, k, eig=eig_h, nthreads=1)
+        dt1 = time.perf_counter() - t1
+        cpu = {
+            "value": round(cpu_qps, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{n_cpu} of {nq} queries x {n_rows_cpu} rows (uint16 row-major codes), "
+                      f"oracle/vaq_oracle.c, OpenMP over queries, {dt:.1f}s"
+                      + ("" if scale == 1.0 else f", scaled x{scale:.4g} to {N} rows"),
+            "single_thread_qps": round(n1 / dt1 * scale, 2),
+        }
+        if world == 1 and n_rows_cpu == n_local:
+            # same inputs: the CPU port is also the parity checker for the bench's own result
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import assert_topk_matches
+            chk = min(n_cpu, 32)
+            Xp = po.project(qh[:chk], eig_h)
+            ad = np.stack([po.all_dists(po.create_lut(Xp[q], cents, max(bits)), host_codes) for q in range(chk)])
+            assert_topk_matches(labels[:chk].cpu().numpy(), dists_[:chk].cpu().numpy(), cl[:chk], cd[:chk], ad,
+                                what="bench parity")
+            cpu["parity_checked_queries"] = chk
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec (ADC search, recall@100 reported alongside)",
+            "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq, "k": k,
+                       "bits": bits, "code_bytes": info["algo_code_bytes"],
+                       "codes": "encoded" if real_codes else "uniform-random",
+                       "sharding": "rows, contiguous; RCCL all-gather of per-shard top-k" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu, "recall": recall,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * vaqhip.h -- C ABI of the MI355X (gfx950) implementation of VAQ's
+ * quantized-distance search path.
+ *
+ * The reference has no FFI layer: the path sits behind C++ member functions
+ * called directly by its drivers.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference checkout).  A C++
+ * adapter with the reference's own names (class VaqHip: search(),
+ * parseMethodString(), public mCodebook-style members) is in
+ * include/vaqhip.hpp; INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary
+ *  - every function returns 0 on success or a negative VAQHIP_E* code; the
+ *    process is never exit()ed or assert()ed (the reference prints and
+ *    exits: VAQ.cpp:64-78, 1263-1266); vaqhip_last_error() gives the text
+ *  - "host" entry points take host pointers and are synchronous;
+ *    "_device" entry points take device pointers on the index's GPU plus a
+ *    hipStream_t (passed as void*), enqueue only, and never synchronise
+ *  - the library has no CPU fallback: without a usable HIP device every call
+ *    fails with VAQHIP_ENODEVICE
+ *  - one index may be used from several host threads; calls on the same
+ *    index are serialised internally
+ */
+#ifndef VAQHIP_H_
+#define VAQHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAQHIP_VERSION 100
+
+/* error codes */
+#define VAQHIP_OK            0
+#define VAQHIP_EINVAL       -1   /* bad argument (null, negative size, ...)                    */
+#define VAQHIP_EUNSUPPORTED -2   /* valid for the reference but outside this build's limits     */
+#define VAQHIP_ENODEVICE    -3   /* no usable HIP device / HIP runtime error at init            */
+#define VAQHIP_ENOMEM       -4   /* device or host allocation failed                            */
+#define VAQHIP_EHIP         -5   /* HIP runtime error during a call                             */
+#define VAQHIP_ERANGE       -6   /* label would not fit the reference's 32-bit int labels       */
+#define VAQHIP_ESTATE       -7   /* call order (e.g. search before codes were added)            */
+
+/* search method bits, numerically equal to VAQ::NNMethod (VAQ.hpp:38-49).
+ * Only HEAP and EA are on this path; both run the same kernel because the
+ * reference's early abandon returns results identical to HEAP
+ * (VAQ.cpp:1694-1727 vs 1729-1758). */
+#define VAQHIP_METHOD_EA   0x02u
+#define VAQHIP_METHOD_HEAP 0x80u
+
+/* limits of this build */
+#define VAQHIP_MAX_SUBSPACES 128
+#define VAQHIP_MAX_BITS      15    /* VAQ.cpp:787-798 dispatches CreateLUT<9..15> */
+#define VAQHIP_MAX_K         1024
+
+typedef struct vaqhip_index vaqhip_index;
+
+/* ---------------------------------------------------------------------------
+ * Index state = the public members VAQ::search reads (VAQ.hpp:51-75):
+ *   D                 mTotalDim (= M * mSubsLen)
+ *   M                 mHighestSubs; must be a multiple of 4 (VAQ.cpp:1741-1746
+ *                     reads four codes per step)
+ *   bits[M]           mBitsAlloc; mCentroidsNum[s] = 1 << bits[s]
+ *   centroids[s]      mCentroidsPerSubs[s], row-major (1<<bits[s]) x (D/M)
+ *   eigvec_real       real part of mEigenVectors, row-major D x D, or NULL for
+ *                     identity (queries already in PCA space)
+ *   device_id         HIP device ordinal the index lives on
+ * Replaces: the state half of `class VAQ` consumed by search(), VAQ.hpp:51-75.
+ * ------------------------------------------------------------------------- */
+int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
+                        const float *const *centroids_rowmajor,
+                        const float *eigvec_real_rowmajor, int device_id);
+
+void vaqhip_index_destroy(vaqhip_index *ix);
+
+/* mCodebook (CodebookType = RowMatrix<uint16_t>, utils/Types.hpp:31), N x M
+ * row-major.  The codes are repacked on the GPU into the bit-packed device
+ * layout (DESIGN.md "Data layout"); the caller keeps ownership of the input.
+ * Replaces the `mCodebook` member filled by VAQ::encode (VAQ.cpp:663-726) or
+ * loadCodebook (utils/IO.hpp:551-571).  Calling it again replaces the codes.
+ * id_base: global row index of local row 0 (shard offset); labels
+ * returned by search are id_base + local row and must stay < 2^31. */
+int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor,
+                               int64_t N, int64_t id_base);
+int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
+                                      int64_t N, int64_t id_base, void *stream);
+
+/* VAQ::search (VAQ.hpp:102, VAQ.cpp:776-847), HEAP / EA semantics:
+ *   queries   nq x D row-major, unprojected (projected by eigvec on the GPU)
+ *   labels    nq x k, ascending by (distance, label); unfilled slots -1
+ *   distances nq x k squared L2 in PCA space (no sqrt, VAQ.cpp:1737-1753);
+ *             unfilled slots FLT_MAX (utils/Heap.hpp:322-349)
+ * Among rows of exactly equal distance the smaller label wins (the
+ * reference's choice there depends on heap internals; DESIGN.md "Ties"). */
+int vaqhip_search(vaqhip_index *ix, const float *queries_rowmajor, int nq, int k,
+                  int32_t *labels, float *distances);
+/* queries already in PCA space (skips ProjectOnEigenVectors, VAQ.hpp:198-201) */
+int vaqhip_search_projected(vaqhip_index *ix, const float *qproj_rowmajor, int nq, int k,
+                            int32_t *labels, float *distances);
+/* device pointers, enqueue on `stream` */
+int vaqhip_search_device(vaqhip_index *ix, const float *d_queries, int nq, int k,
+                         int projected, int32_t *d_labels, float *d_distances,
+                         void *stream);
+
+/* Test hook for VAQ::CreateLUT<maxbit> (VAQ.hpp:128-167): writes, per query,
+ * the reference LUTType (column-major ksub x M, ksub = 1 << max(bits), rows
+ * >= 1<<bits[s] zero): lut_out[q*M*ksub + s*ksub + c]. */
+int vaqhip_build_lut(vaqhip_index *ix, const float *queries_rowmajor, int nq,
+                     int projected, float *lut_out);
+
+/* VAQ::ProjectOnEigenVectors (VAQ.hpp:198-201): out = X * real(eigvec). */
+int vaqhip_project(vaqhip_index *ix, const float *X_rowmajor, int64_t n, float *out);
+
+/* Multi-GPU exchange step: after an all-gather of per-shard
+ * results laid out [n_lists][nq][k] (labels already global), keep per query
+ * the k smallest by (distance, label).  Device pointers.  The reference's
+ * precedent for shard-and-merge: BitVecEngine.cpp:1034-1132 (:1114-1126). */
+int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists,
+                             const int32_t *d_label_lists, int n_lists, int nq, int k,
+                             int32_t *d_labels_out, float *d_dist_out, void *stream);
+
+/* ----- introspection / tuning -------------------------------------------- */
+typedef struct {
+  int D, M, L;
+  int max_bits;        /* mMaxBitsPerSubs                                   */
+  int total_bits;      /* sum of bits                                       */
+  int code_bytes;      /* packed bytes per row on the device                */
+  int algo_code_bytes; /* ceil(total_bits / 8): the roofline's byte figure  */
+  int lut_floats;      /* sum of 1<<bits[s]: packed LUT entries per query   */
+  int64_t N;
+  int64_t id_base;
+  int device_id;
+  int layout;          /* 0 = one byte per subspace (all bits == 8), 1 = bit-packed */
+} vaqhip_info;
+int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
+
+/* Options (all optional; defaults chosen per launch):
+ *   "queries_per_pass"  Qb in {0 = auto, 1, 2, 4}: queries served by one
+ *                       streaming pass of a workgroup over its code slice
+ *   "slices"            0 = auto, else number of row slices per query batch
+ *   "timing"            1: record hipEvents (on the search's own stream) around
+ *                       each kernel of every following search, up to 256
+ *                       searches between two vaqhip_last_timing reads
+ *   "candidate_capacity" 0 = auto, else per-wavefront candidate slots (power of 2) */
+int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
+
+typedef struct {
+  float project_ms, lut_ms, scan_ms, merge_ms; /* mean device time per search over the
+                                                  searches recorded since the last read  */
+  int n_searches;                              /* how many searches that mean covers   */
+  int queries_per_pass;                        /* Qb actually used              */
+  int slices;                                  /* row slices per query batch    */
+  int workgroups;                              /* scan kernel grid size         */
+  int passes;                                  /* ceil(nq / Qb)                 */
+  int lds_bytes;                               /* LDS per scan workgroup        */
+} vaqhip_timing;
+int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
+
+const char *vaqhip_last_error(void);
+int vaqhip_version(void);
+/* number of HIP devices visible, or a negative error code */
+int vaqhip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAQHIP_H_ */

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/liboracle.so), built on demand with gcc."""
+    from oracle import pyoracle
+    pyoracle.build(ref=True)
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def vaqlib():
+    """The product library; built on demand with hipcc (cross-compiles without a GPU)."""
+    from vaq_amd import build, _lib
+    build.build_lib()
+    return _lib.load()

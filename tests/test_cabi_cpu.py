@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the shared library builds for gfx950,
+loads, exports every symbol include/vaqhip.h declares, and fails loudly (no
+CPU fallback) when there is no GPU.  No compute is attempted here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "vaqhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vaqhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported(vaqlib):
+    from vaq_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(vaqlib, s), f"{s} declared in include/vaqhip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_version_and_error_string(vaqlib):
+    assert vaqlib.vaqhip_version() == 100
+    assert isinstance(vaqlib.vaqhip_last_error(), bytes)
+
+
+def _no_gpu(vaqlib):
+    return vaqlib.vaqhip_device_count() <= 0
+
+
+def test_no_cpu_fallback_without_gpu(vaqlib):
+    if not _no_gpu(vaqlib):
+        pytest.skip("a GPU is present")
+    import vaq_amd
+    v = vaq_amd.VaqHip()
+    v.mBitsAlloc = [8] * 4
+    v.mCentroidsPerSubs = [np.zeros((256, 2), np.float32)] * 4
+    v.mCodebook = np.zeros((10, 4), np.uint16)
+    with pytest.raises(vaq_amd.VaqHipError) as e:
+        v.search(np.zeros((1, 8), np.float32), 1)
+    assert e.value.code == -3  # VAQHIP_ENODEVICE
+
+
+def test_argument_validation_does_not_need_gpu(vaqlib):
+    h = C.c_void_p()
+    bits = (C.c_int * 6)(*[8] * 6)
+    arr = (C.POINTER(C.c_float) * 6)()
+    rc = vaqlib.vaqhip_index_create(C.byref(h), 12, 6, bits, arr, None, 0)
+    assert rc == -1 and b"4 codes per step" in vaqlib.vaqhip_last_error()
+    rc = vaqlib.vaqhip_index_create(C.byref(h), 13, 4, bits, arr, None, 0)
+    assert rc == -1
+    rc = vaqlib.vaqhip_index_create(None, 8, 4, bits, arr, None, 0)
+    assert rc == -1
+    assert vaqlib.vaqhip_search(None, None, 1, 1, None, None) == -1
+
+
+def test_parse_method_string():
+    import vaq_amd
+    v = vaq_amd.VaqHip()
+    v.parseMethodString("VAQ256m32min7max8var1,HEAP")
+    assert (v.mBitBudget, v.mSubspaceNum, v.mMinBitsPerSubs, v.mMaxBitsPerSubs) == (256, 32, 7, 8)
+    assert v.mMethods == vaq_amd.NNMethod.Heap
+    v.parseMethodString("VAQ64m16min3max6var0.99,EA")
+    assert v.mMethods == vaq_amd.NNMethod.EA and abs(v.mPercentVarExplained - 0.99) < 1e-6
+    with pytest.raises(vaq_amd.VaqHipError):
+        v.parseMethodString("VAQ128m32min6max9var0.95,EA_TI200")
+    with pytest.raises(vaq_amd.VaqHipError):
+        v.parseMethodString("VAQ128m32min2max4var1,FAST")

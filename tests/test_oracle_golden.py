@@ -1,0 +1,152 @@
+"""CPU tests: the oracle (oracle/vaq_oracle.c) against the committed golden
+vectors and, where oracle/_ref was built from /root/reference, against the
+reference's own code."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_topk_matches, make_case
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(json.load(open(os.path.join(GOLD, "manifest.json"))).keys())
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    bits = z["bits"].tolist()
+    cents = [z[f"cent{s}"] for s in range(len(bits))]
+    return z, bits, cents
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(oracle, name):
+    z, bits, cents = load_case(name)
+    Xp = oracle.project(z["X"], z["eig"])
+    assert np.array_equal(Xp.view(np.uint32), z["Xproj"].view(np.uint32))
+    for q in range(Xp.shape[0]):
+        lut = oracle.create_lut(Xp[q], cents, max(bits))
+        assert np.array_equal(lut.view(np.uint32), z["lut"][q].view(np.uint32))
+    for key in z.files:
+        if not key.startswith("labels_k"):
+            continue
+        k = int(key[len("labels_k"):])
+        for method in (oracle.METHOD_HEAP, oracle.METHOD_EA):
+            labels, dists = oracle.search(z["X"], cents, z["codes"], k, eig=z["eig"],
+                                          max_bits=max(bits), method=method)
+            assert np.array_equal(labels, z[key])
+            assert np.array_equal(dists.view(np.uint32), z[f"dists_k{k}"].view(np.uint32))
+
+
+def test_golden_has_boundary_ties():
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))
+    assert sum(v["boundary_tie_queries"] for v in man.values()) > 0
+
+
+def test_heap_against_reference_heap(oracle):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        n = int(rng.integers(1, 4000))
+        k = int(rng.integers(1, 200))
+        d = rng.integers(0, 12, n).astype(np.float32) if trial % 2 else rng.random(n).astype(np.float32)
+        a = oracle.topk_from_dists(d, k)
+        b = oracle.ref_topk_from_dists(d, k)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    ids = rng.permutation(5000).astype(np.int32)
+    d = rng.integers(0, 30, 5000).astype(np.float32)
+    a = oracle.topk_from_dists(d, 64, ids)
+    b = oracle.ref_topk_from_dists(d, 64, ids)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_lut_against_reference_primitives(oracle):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(11)
+    for K, L in [(256, 16), (4096, 16), (16, 8), (8, 4), (64, 1), (512, 32)]:
+        cent = (rng.normal(size=(K, L)) * 30).astype(np.float32)
+        q = (rng.normal(size=L) * 30).astype(np.float32)
+        lut = oracle.create_lut(np.tile(q, 4), [cent] * 4, int(np.log2(K)))
+        r = oracle.ref_lut_column_fma(q, cent)
+        assert np.array_equal(lut[2, :K].view(np.uint32), r.view(np.uint32))
+    for L in [1, 2, 4, 8, 12, 16, 3, 5]:
+        for K in [2, 4]:
+            cent = (rng.normal(size=(K, L)) * 30).astype(np.float32)
+            q = (rng.normal(size=L) * 30).astype(np.float32)
+            lut = oracle.create_lut(np.tile(q, 4), [cent] * 4, 3)
+            r = oracle.ref_l2sqr_ny(q, cent)
+            assert np.array_equal(lut[1, :K].view(np.uint32), r.view(np.uint32))
+
+
+def test_heap_equals_sort_contract(oracle):
+    """On tie-free data HEAP output == plain (dist, id) sort; with ties the
+    difference is confined to tie runs (hard parts)."""
+    c = make_case(21, 64, [8] * 8, 6000, 6)
+    Xp = oracle.project(c["X"], c["eig"])
+    labels, dists = oracle.search(Xp, c["cents"], c["codes"], 50, projected=True)
+    for q in range(6):
+        lut = oracle.create_lut(Xp[q], c["cents"], 8)
+        ad = oracle.all_dists(lut, c["codes"])
+        order = np.lexsort((np.arange(len(ad)), ad))[:50]
+        assert np.array_equal(order.astype(np.int32), labels[q])
+        assert np.array_equal(ad[order], dists[q])
+
+
+def test_ea_equals_heap(oracle):
+    c = make_case(22, 32, [4] * 8, 3000, 5, integer=True)
+    a = oracle.search(c["X"], c["cents"], c["codes"], 40, eig=c["eig"], method=oracle.METHOD_HEAP)
+    b = oracle.search(c["X"], c["cents"], c["codes"], 40, eig=c["eig"], method=oracle.METHOD_EA)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_openmp_matches_single_thread(oracle):
+    c = make_case(23, 64, [8] * 8, 5000, 16)
+    a = oracle.search(c["X"], c["cents"], c["codes"], 20, eig=c["eig"], nthreads=1)
+    b = oracle.search(c["X"], c["cents"], c["codes"], 20, eig=c["eig"], nthreads=4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_m_not_multiple_of_4_rejected(oracle):
+    c = make_case(24, 12, [4] * 6, 100, 2)
+    with pytest.raises(ValueError):
+        oracle.search(c["X"], c["cents"], c["codes"], 5, eig=c["eig"])
+
+
+def test_recall_against_reference(oracle):
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, 500, size=(20, 10)).astype(np.int32)
+    gt = rng.integers(0, 500, size=(20, 100)).astype(np.int32)
+    gt[:, :5] = labels[:, :5]
+    a = oracle.avg_recall(labels, gt)
+    b = oracle.recall_at_r(labels, gt)
+    assert 0.5 <= a <= 1.0 and b == 1.0
+    from vaq_amd import harness
+    # harness recall (set-based) equals the reference's definition when ids are unique per row
+    lab_u = np.stack([rng.permutation(500)[:10] for _ in range(20)]).astype(np.int32)
+    gt_u = np.stack([rng.permutation(500)[:100] for _ in range(20)]).astype(np.int32)
+    assert abs(harness.avg_recall(lab_u, gt_u) - oracle.avg_recall(lab_u, gt_u)) < 1e-12
+    if oracle.have_ref():
+        import ctypes as C
+        r = oracle.ref()
+        ra = r.ref_avg_recall(labels.ctypes.data_as(C.POINTER(C.c_int)), 20, 10,
+                              gt.ctypes.data_as(C.POINTER(C.c_int)), 100)
+        rb = r.ref_recall_at_r(labels.ctypes.data_as(C.POINTER(C.c_int)), 20, 10,
+                               gt.ctypes.data_as(C.POINTER(C.c_int)), 100)
+        assert ra == a and rb == b
+
+
+def test_refine_restatement(oracle):
+    rng = np.random.default_rng(5)
+    Xtr = rng.normal(size=(400, 24)).astype(np.float32)
+    Xq = rng.normal(size=(6, 24)).astype(np.float32)
+    cand = np.stack([rng.permutation(400)[:50] for _ in range(6)]).astype(np.int32)
+    labels, dists = oracle.refine(Xq, Xtr, cand, 10)
+    for q in range(6):
+        d = ((Xq[q][None, :] - Xtr[cand[q]]) ** 2).sum(1)
+        best = cand[q][np.argsort(d, kind="stable")[:10]]
+        assert set(best.tolist()) == set(labels[q].tolist())
+        assert np.all(np.diff(dists[q]) >= 0)

@@ -1,0 +1,94 @@
+"""ctypes binding of include/vaqhip.h (vaq_amd/lib/libvaqhip.so).
+
+The library is loaded lazily and the load FAILS LOUDLY when the shared object
+is missing: there is no Python/NumPy fallback for any entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libvaqhip.so")
+
+# every symbol include/vaqhip.h declares
+SYMBOLS = [
+    "vaqhip_index_create", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
+    "vaqhip_index_set_codes_u16_device", "vaqhip_search", "vaqhip_search_projected",
+    "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
+    "vaqhip_index_info", "vaqhip_set_option", "vaqhip_last_timing", "vaqhip_last_error",
+    "vaqhip_version", "vaqhip_device_count",
+]
+
+ERROR_NAMES = {
+    -1: "EINVAL", -2: "EUNSUPPORTED", -3: "ENODEVICE", -4: "ENOMEM", -5: "EHIP",
+    -6: "ERANGE", -7: "ESTATE",
+}
+
+
+class VaqHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vaqhip error {code} ({ERROR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [("D", C.c_int), ("M", C.c_int), ("L", C.c_int), ("max_bits", C.c_int),
+                ("total_bits", C.c_int), ("code_bytes", C.c_int), ("algo_code_bytes", C.c_int),
+                ("lut_floats", C.c_int), ("N", C.c_int64), ("id_base", C.c_int64),
+                ("device_id", C.c_int), ("layout", C.c_int)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("project_ms", C.c_float), ("lut_ms", C.c_float), ("scan_ms", C.c_float),
+                ("merge_ms", C.c_float), ("n_searches", C.c_int), ("queries_per_pass", C.c_int), ("slices", C.c_int),
+                ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Return the loaded C-ABI library; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -m vaq_amd.build` "
+            "(hipcc, gfx950). vaq_amd has no CPU fallback.")
+    L = C.CDLL(_LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.vaqhip_index_create.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(i32),
+                                      C.POINTER(C.POINTER(C.c_float)), vp, i32]
+    L.vaqhip_index_destroy.argtypes = [vp]
+    L.vaqhip_index_destroy.restype = None
+    L.vaqhip_index_set_codes_u16.argtypes = [vp, vp, i64, i64]
+    L.vaqhip_index_set_codes_u16_device.argtypes = [vp, vp, i64, i64, vp]
+    L.vaqhip_search.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.vaqhip_search_projected.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.vaqhip_search_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.vaqhip_build_lut.argtypes = [vp, vp, i32, i32, vp]
+    L.vaqhip_project.argtypes = [vp, vp, i64, vp]
+    L.vaqhip_merge_topk_device.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.vaqhip_index_info.argtypes = [vp, C.POINTER(Info)]
+    L.vaqhip_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.vaqhip_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.vaqhip_last_error.restype = C.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int:
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        msg = load().vaqhip_last_error()
+        raise VaqHipError(rc, msg.decode() if msg else "")
+    return rc

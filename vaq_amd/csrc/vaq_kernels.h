@@ -1,0 +1,81 @@
+// vaq_kernels.h -- launch interface between the C-ABI host code
+// (vaqhip_api.cpp) and the gfx950 kernels (vaq_kernels.hip).
+#ifndef VAQ_KERNELS_H_
+#define VAQ_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vaq {
+
+// Per-subspace descriptor, one table per index in device memory.
+struct SubDesc {
+  int ncent;    // mCentroidsNum[s] = 1 << bits
+  int bits;     // mBitsAlloc[s]
+  int bit_off;  // first bit of the field inside a packed row (LSB-first)
+  int lut_off;  // entry offset inside the packed per-query LUT
+  int cent_off; // float offset inside the concatenated centroid buffer
+  int word;     // bit_off / 32
+  int shift;    // bit_off % 32
+  int pad;
+};
+
+enum Layout { LAYOUT_BYTES = 0, LAYOUT_BITS = 1 };
+
+// rows per planar tile of the bit-packed layout (one wavefront step)
+constexpr int TILE_ROWS = 64;
+// wavefronts per scan workgroup
+constexpr int SCAN_WAVES = 4;
+// sentinel id of an empty candidate slot (sorts after every real id)
+constexpr int ID_SENTINEL = 0x7fffffff;
+
+struct ScanParams {
+  const uint32_t *codes;  // packed codes (layout-specific)
+  int64_t n_rows;         // local rows
+  int layout;             // Layout
+  int M;                  // subspaces
+  int W;                  // dwords per row (bit-packed layout)
+  const SubDesc *sub;     // [M]
+  const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
+  const float *lut;       // [nq][lut_floats]
+  int lut_floats;
+  int nq;
+  int k;
+  int kcap;               // per-wave candidate capacity (power of two, >= k + 64)
+  int qb;                 // queries per pass (1, 2, 4)
+  int n_slices;           // row slices per query batch
+  int64_t slice_rows;     // rows per slice (multiple of the workgroup step)
+  float *part_d;          // [nq][n_slices*SCAN_WAVES][k]
+  int *part_id;
+};
+
+hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
+                          hipStream_t st);
+hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,
+                            const SubDesc *sub, const float *cent, int lut_floats,
+                            float *lut, hipStream_t st);
+hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDesc *sub,
+                             int lut_floats, int ksub, float *lut_ref, hipStream_t st);
+// dwords the packed layout needs for `rows` rows
+int64_t packed_words(int64_t rows, int M, int layout, int W);
+// Pack rows [row_begin, row_end) (codes_u16 points at row_begin; row_begin a
+// multiple of 64) and zero-fill the packed words up to out_row_end.
+hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64_t row_end,
+                             int64_t out_row_end, int M, int layout, int W, const SubDesc *sub,
+                             uint32_t *out, hipStream_t st);
+// bytes of LDS a scan workgroup needs, or 0 when the configuration is unsupported
+size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int kcap);
+// rows one workgroup step covers (slice_rows must be a multiple of it)
+int scan_wg_step_rows(int layout, int M);
+// rows one wavefront can admit per query between two prune checks
+int scan_admit_per_step(int layout, int M);
+hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
+// in_final != 0: inputs use the API's -1 / FLT_MAX convention for empty slots
+// candidate i of list l of query q sits at l*list_stride + q*query_stride + i
+hipError_t launch_merge(const float *part_d, const int *part_id, int n_lists,
+                        int64_t list_stride, int64_t query_stride, int nq, int k,
+                        int64_t id_base, int in_final, int32_t *labels, float *dist,
+                        hipStream_t st);
+
+} // namespace vaq
+#endif

@@ -1,0 +1,609 @@
+// vaqhip_api.cpp -- host side of the C ABI declared in include/vaqhip.h.
+// Owns device memory, picks launch geometry, enqueues the gfx950 kernels of
+// vaq_kernels.hip.  There is no CPU path here: every entry point needs a HIP
+// device and fails with VAQHIP_ENODEVICE / VAQHIP_EHIP otherwise.
+#include "vaqhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vaq_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? VAQHIP_ENOMEM : VAQHIP_EHIP, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                 \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // grow-only
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    else p = nullptr;
+    return e;
+  }
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
+constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
+constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
+constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
+
+} // namespace
+
+struct vaqhip_index {
+  int D = 0, M = 0, L = 0;
+  int max_bits = 0, total_bits = 0, W = 0, layout = 0, lut_floats = 0;
+  int device = 0, n_cu = 256;
+  std::vector<int> bits;
+  std::vector<vaq::SubDesc> sub;
+  DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes;
+  bool has_eig = false;
+  int64_t N = -1, id_base = 0;
+  // workspace (grow-only, reused across searches)
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref;
+  hipStream_t stream = nullptr;
+  // options
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_kcap = 0;
+  // timing: a ring of 5-event sets, one per search since the last read
+  static constexpr int EV_SETS = 256;
+  std::vector<hipEvent_t> ev;   // EV_SETS * 5, created on first use
+  int ev_used = 0;              // searches recorded since the last vaqhip_last_timing
+  vaqhip_timing last = {};
+  std::mutex mu;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+struct Plan {
+  int qb, kcap, n_slices;
+  int64_t slice_rows;
+  size_t lds;
+};
+
+int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
+  const int admit = vaq::scan_admit_per_step(ix->layout, ix->M);
+  const int kcap_min = next_pow2(k + admit);
+  int kcap = ix->opt_kcap > 0 ? std::max(next_pow2(ix->opt_kcap), kcap_min)
+                              : next_pow2(k + admit + std::max(64, k));
+  int qb = ix->opt_qb > 0 ? ix->opt_qb : 2;
+  if (nq < qb) qb = nq >= 2 ? 2 : 1;
+  if (qb == 3) qb = 2;
+  // fit LDS: first shrink the candidate buffers, then the query batch
+  for (;;) {
+    size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, kcap);
+    if (lds <= LDS_LIMIT) break;
+    if (kcap > kcap_min) kcap >>= 1;
+    else if (qb > 1) qb >>= 1;
+    else
+      return fail(VAQHIP_EUNSUPPORTED,
+                  "lookup tables of %d floats plus top-%d buffers need %zu B of LDS (> %zu)",
+                  ix->lut_floats, k, lds, LDS_LIMIT);
+  }
+  pl->qb = qb;
+  pl->kcap = kcap;
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, kcap);
+  const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
+  const int64_t N = ix->N;
+  const int nqb = (nq + qb - 1) / qb;
+  int64_t s;
+  if (ix->opt_slices > 0) s = ix->opt_slices;
+  else {
+    const int64_t target = (int64_t)ix->n_cu * 8;  // workgroups wanted in flight
+    s = (target + nqb - 1) / nqb;
+    const int64_t max_s = std::max<int64_t>(1, N / MIN_SLICE_ROWS);
+    s = std::min(s, max_s);
+  }
+  s = std::max<int64_t>(1, s);
+  int64_t rows = (N + s - 1) / s;
+  rows = std::max<int64_t>(step, ((rows + step - 1) / step) * step);
+  s = N > 0 ? (N + rows - 1) / rows : 1;
+  pl->n_slices = (int)s;
+  pl->slice_rows = rows;
+  return VAQHIP_OK;
+}
+
+int ensure_events(vaqhip_index *ix) {
+  if (!ix->ev.empty()) return VAQHIP_OK;
+  std::vector<hipEvent_t> ev(vaqhip_index::EV_SETS * 5);
+  for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+  ix->ev.swap(ev);
+  return VAQHIP_OK;
+}
+
+// core: device pointers in, device pointers out, enqueue only
+int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                         int32_t *d_labels, float *d_dist, hipStream_t st) {
+  if (ix->N < 0) return fail(VAQHIP_ESTATE, "search before codes were set");
+  if (nq < 0 || k <= 0) return fail(VAQHIP_EINVAL, "nq=%d k=%d", nq, k);
+  if (k > VAQHIP_MAX_K) return fail(VAQHIP_EUNSUPPORTED, "k=%d > %d", k, VAQHIP_MAX_K);
+  if (nq == 0) return VAQHIP_OK;
+  if (!d_queries || !d_labels || !d_dist) return fail(VAQHIP_EINVAL, "null pointer");
+
+  bool timing = ix->opt_timing != 0;
+  hipEvent_t *ev = nullptr;
+  if (timing) {
+    int rc = ensure_events(ix);
+    if (rc) return rc;
+    if (ix->ev_used >= vaqhip_index::EV_SETS) timing = false;  // ring full: stop recording
+    else ev = ix->ev.data() + (size_t)ix->ev_used * 5;
+  }
+  vaqhip_timing tm = {};
+  Plan pl;
+  {
+    int rc = make_plan(ix, std::min(nq, QUERY_CHUNK), k, &pl);
+    if (rc) return rc;
+  }
+  const int chunk = std::min(nq, QUERY_CHUNK);
+  const bool do_project = !projected && ix->has_eig;
+  if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
+  const int nslots = pl.n_slices * vaq::SCAN_WAVES;
+  HIP_TRY(ix->w_part_d.ensure((size_t)chunk * nslots * k * sizeof(float)));
+  HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
+
+  if (timing && nq > chunk)
+    return fail(VAQHIP_EUNSUPPORTED, "timing supports at most %d queries per call", QUERY_CHUNK);
+
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int n = std::min(chunk, nq - q0);
+    const float *dq = d_queries + (size_t)q0 * ix->D;
+    const float *qp = dq;
+    if (timing) HIP_TRY(hipEventRecord(ev[0], st));
+    if (do_project) {
+      HIP_TRY(vaq::launch_project(dq, n, ix->D, ix->d_eig.as<float>(), ix->w_qproj.as<float>(), st));
+      qp = ix->w_qproj.as<float>();
+    }
+    if (timing) HIP_TRY(hipEventRecord(ev[1], st));
+    HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
+                                  ix->d_cent.as<float>(), ix->lut_floats, ix->w_lut.as<float>(), st));
+    if (timing) HIP_TRY(hipEventRecord(ev[2], st));
+    vaq::ScanParams sp;
+    sp.codes = ix->d_codes.as<uint32_t>();
+    sp.n_rows = ix->N;
+    sp.layout = ix->layout;
+    sp.M = ix->M;
+    sp.W = ix->W;
+    sp.sub = ix->d_sub.as<vaq::SubDesc>();
+    sp.first_sub = ix->d_first_sub.as<int>();
+    sp.lut = ix->w_lut.as<float>();
+    sp.lut_floats = ix->lut_floats;
+    sp.nq = n;
+    sp.k = k;
+    sp.kcap = pl.kcap;
+    sp.qb = pl.qb;
+    sp.n_slices = pl.n_slices;
+    sp.slice_rows = pl.slice_rows;
+    sp.part_d = ix->w_part_d.as<float>();
+    sp.part_id = ix->w_part_id.as<int>();
+    int grid = 0;
+    if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+    if (timing) HIP_TRY(hipEventRecord(ev[3], st));
+    const int lists = ix->N > 0 ? nslots : 0;
+    HIP_TRY(vaq::launch_merge(ix->w_part_d.as<float>(), ix->w_part_id.as<int>(), lists, k,
+                              (int64_t)nslots * k, n, k, ix->id_base, 0,
+                              d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st));
+    if (timing) HIP_TRY(hipEventRecord(ev[4], st));
+    tm.queries_per_pass = pl.qb;
+    tm.slices = pl.n_slices;
+    tm.workgroups = grid;
+    tm.passes = (n + pl.qb - 1) / pl.qb;
+    tm.lds_bytes = (int)pl.lds;
+  }
+  tm.n_searches = 0;
+  ix->last = tm;
+  if (timing) ix->ev_used++;
+  return VAQHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *vaqhip_last_error(void) { return g_err.c_str(); }
+int vaqhip_version(void) { return VAQHIP_VERSION; }
+
+int vaqhip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(VAQHIP_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
+                        const float *const *centroids, const float *eig, int device_id) {
+  if (!out) return fail(VAQHIP_EINVAL, "out is null");
+  *out = nullptr;
+  if (D <= 0 || M <= 0 || !bits || !centroids) return fail(VAQHIP_EINVAL, "bad D/M/bits/centroids");
+  if (M > VAQHIP_MAX_SUBSPACES) return fail(VAQHIP_EUNSUPPORTED, "M=%d > %d", M, VAQHIP_MAX_SUBSPACES);
+  if (M % 4 != 0)
+    return fail(VAQHIP_EINVAL, "M=%d: the reference scan reads 4 codes per step (VAQ.cpp:1741-1746)", M);
+  if (D % M != 0) return fail(VAQHIP_EINVAL, "D=%d is not a multiple of M=%d", D, M);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(VAQHIP_ENODEVICE, "no HIP device available (this library has no CPU path)");
+  if (device_id < 0 || device_id >= ndev) return fail(VAQHIP_EINVAL, "device_id=%d of %d", device_id, ndev);
+
+  vaqhip_index *ix = new (std::nothrow) vaqhip_index();
+  if (!ix) return fail(VAQHIP_ENOMEM, "host allocation");
+  struct Cleanup {
+    vaqhip_index *p;
+    ~Cleanup() { if (p) vaqhip_index_destroy(p); }
+  } cleanup{ix};
+  ix->D = D;
+  ix->M = M;
+  ix->L = D / M;
+  ix->device = device_id;
+  ix->bits.assign(bits, bits + M);
+  ix->sub.resize(M);
+  int bit_off = 0, lut_off = 0, cent_off = 0, maxb = 0;
+  bool all8 = true;
+  for (int s = 0; s < M; s++) {
+    const int b = bits[s];
+    if (b < 1 || b > VAQHIP_MAX_BITS) return fail(VAQHIP_EINVAL, "bits[%d]=%d outside 1..%d", s, b, VAQHIP_MAX_BITS);
+    if (!centroids[s]) return fail(VAQHIP_EINVAL, "centroids[%d] is null", s);
+    vaq::SubDesc &sd = ix->sub[s];
+    sd.ncent = 1 << b;
+    sd.bits = b;
+    sd.bit_off = bit_off;
+    sd.lut_off = lut_off;
+    sd.cent_off = cent_off;
+    sd.word = bit_off / 32;
+    sd.shift = bit_off % 32;
+    sd.pad = 0;
+    bit_off += b;
+    lut_off += sd.ncent;
+    cent_off += sd.ncent * ix->L;
+    maxb = std::max(maxb, b);
+    all8 = all8 && b == 8;
+  }
+  ix->max_bits = maxb;
+  ix->total_bits = bit_off;
+  ix->lut_floats = lut_off;
+  ix->W = (bit_off + 31) / 32;
+  ix->layout = (all8 && (M == 8 || M == 16 || M == 32)) ? vaq::LAYOUT_BYTES : vaq::LAYOUT_BITS;
+  if (ix->layout == vaq::LAYOUT_BITS && ix->W > 8)
+    return fail(VAQHIP_EUNSUPPORTED, "%d code bits per row; this build packs at most 256", bit_off);
+  std::vector<int> first_sub(ix->W + 1, M);
+  first_sub[0] = 0;
+  for (int w = 1; w <= ix->W; w++) {
+    int f = M;
+    for (int s = 0; s < M; s++)
+      if (ix->sub[s].bit_off >= 32 * w) { f = s; break; }
+    first_sub[w] = f;
+  }
+
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+    ix->n_cu = prop.multiProcessorCount;
+  HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  HIP_TRY(ix->d_cent.ensure((size_t)cent_off * sizeof(float)));
+  for (int s = 0; s < M; s++)
+    HIP_TRY(hipMemcpy(ix->d_cent.as<float>() + ix->sub[s].cent_off, centroids[s],
+                      (size_t)ix->sub[s].ncent * ix->L * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(ix->d_sub.ensure(M * sizeof(vaq::SubDesc)));
+  HIP_TRY(hipMemcpy(ix->d_sub.p, ix->sub.data(), M * sizeof(vaq::SubDesc), hipMemcpyHostToDevice));
+  HIP_TRY(ix->d_first_sub.ensure(first_sub.size() * sizeof(int)));
+  HIP_TRY(hipMemcpy(ix->d_first_sub.p, first_sub.data(), first_sub.size() * sizeof(int),
+                    hipMemcpyHostToDevice));
+  if (eig) {
+    HIP_TRY(ix->d_eig.ensure((size_t)D * D * sizeof(float)));
+    HIP_TRY(hipMemcpy(ix->d_eig.p, eig, (size_t)D * D * sizeof(float), hipMemcpyHostToDevice));
+    ix->has_eig = true;
+  }
+  cleanup.p = nullptr;
+  *out = ix;
+  return VAQHIP_OK;
+}
+
+void vaqhip_index_destroy(vaqhip_index *ix) {
+  if (!ix) return;
+  {
+    DeviceGuard g(ix->device);
+    if (ix->stream) {
+      (void)hipStreamSynchronize(ix->stream);
+      (void)hipStreamDestroy(ix->stream);
+    }
+    for (auto &e : ix->ev) (void)hipEventDestroy(e);
+    for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->w_q,
+                      &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_labels,
+                      &ix->w_dist, &ix->w_stage, &ix->w_lutref})
+      b->release();
+  }
+  delete ix;
+}
+
+static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_device, int64_t N,
+                            int64_t id_base, hipStream_t st) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (N < 0 || (N > 0 && !codes)) return fail(VAQHIP_EINVAL, "bad codes/N");
+  if (id_base < 0) return fail(VAQHIP_EINVAL, "id_base < 0");
+  if (N > 0x7fffffffLL - 1 || id_base + N > 0x7fffffffLL)
+    return fail(VAQHIP_ERANGE, "labels are 32-bit ints (utils/Types.hpp:100): id_base+N = %lld",
+                (long long)(id_base + N));
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
+  const int64_t padded = std::max<int64_t>(step, ((N + step - 1) / step) * step);
+  const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
+  HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
+  const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
+  if (N == 0) {
+    HIP_TRY(hipMemsetAsync(ix->d_codes.p, 0, (size_t)words * sizeof(uint32_t), st));
+  } else if (on_device) {
+    HIP_TRY(vaq::launch_pack_codes(codes, 0, N, padded, ix->M, ix->layout, ix->W, dsub,
+                                   ix->d_codes.as<uint32_t>(), st));
+  } else {
+    const int64_t chunk = std::min<int64_t>(N, UPLOAD_CHUNK_ROWS);
+    HIP_TRY(ix->w_stage.ensure((size_t)chunk * ix->M * sizeof(uint16_t)));
+    for (int64_t r = 0; r < N; r += chunk) {
+      const int64_t e = std::min(N, r + chunk);
+      HIP_TRY(hipMemcpyAsync(ix->w_stage.p, codes + r * ix->M, (size_t)(e - r) * ix->M * sizeof(uint16_t),
+                             hipMemcpyHostToDevice, st));
+      HIP_TRY(vaq::launch_pack_codes(ix->w_stage.as<uint16_t>(), r, e, e == N ? padded : e, ix->M,
+                                     ix->layout, ix->W, dsub, ix->d_codes.as<uint32_t>(), st));
+      HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused
+    }
+  }
+  ix->N = N;
+  ix->id_base = id_base;
+  return VAQHIP_OK;
+}
+
+int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes, int64_t N, int64_t id_base) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  int rc = set_codes_common(ix, codes, false, N, id_base, ix->stream);
+  if (rc) return rc;
+  DeviceGuard g(ix->device);
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return VAQHIP_OK;
+}
+
+int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes, int64_t N,
+                                      int64_t id_base, void *stream) {
+  return set_codes_common(ix, d_codes, true, N, id_base, static_cast<hipStream_t>(stream));
+}
+
+int vaqhip_search_device(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                         int32_t *d_labels, float *d_dist, void *stream) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  return search_device_locked(ix, d_queries, nq, k, projected, d_labels, d_dist,
+                              static_cast<hipStream_t>(stream));
+}
+
+static int search_host(vaqhip_index *ix, const float *queries, int nq, int k, int projected,
+                       int32_t *labels, float *distances) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (nq < 0 || k <= 0) return fail(VAQHIP_EINVAL, "nq=%d k=%d", nq, k);
+  if (nq == 0) return VAQHIP_OK;
+  if (!queries || !labels || !distances) return fail(VAQHIP_EINVAL, "null pointer");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  const size_t qbytes = (size_t)nq * ix->D * sizeof(float);
+  const size_t rbytes = (size_t)nq * k * sizeof(float);
+  HIP_TRY(ix->w_q.ensure(qbytes));
+  HIP_TRY(ix->w_labels.ensure(rbytes));
+  HIP_TRY(ix->w_dist.ensure(rbytes));
+  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, qbytes, hipMemcpyHostToDevice, ix->stream));
+  int rc = search_device_locked(ix, ix->w_q.as<float>(), nq, k, projected, ix->w_labels.as<int32_t>(),
+                                ix->w_dist.as<float>(), ix->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(labels, ix->w_labels.p, rbytes, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipMemcpyAsync(distances, ix->w_dist.p, rbytes, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return VAQHIP_OK;
+}
+
+int vaqhip_search(vaqhip_index *ix, const float *queries, int nq, int k, int32_t *labels,
+                  float *distances) {
+  return search_host(ix, queries, nq, k, 0, labels, distances);
+}
+
+int vaqhip_search_projected(vaqhip_index *ix, const float *qproj, int nq, int k, int32_t *labels,
+                            float *distances) {
+  return search_host(ix, qproj, nq, k, 1, labels, distances);
+}
+
+int vaqhip_project(vaqhip_index *ix, const float *X, int64_t n, float *out) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (n < 0 || (n > 0 && (!X || !out))) return fail(VAQHIP_EINVAL, "bad arguments");
+  if (n == 0) return VAQHIP_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  if (!ix->has_eig) {
+    std::memcpy(out, X, (size_t)n * ix->D * sizeof(float));
+    return VAQHIP_OK;
+  }
+  const int64_t chunk = std::min<int64_t>(n, 1 << 20);
+  HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
+  HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  for (int64_t r = 0; r < n; r += chunk) {
+    const int64_t m = std::min(chunk, n - r);
+    const size_t bytes = (size_t)m * ix->D * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(ix->w_q.p, X + r * ix->D, bytes, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(vaq::launch_project(ix->w_q.as<float>(), m, ix->D, ix->d_eig.as<float>(),
+                                ix->w_qproj.as<float>(), ix->stream));
+    HIP_TRY(hipMemcpyAsync(out + r * ix->D, ix->w_qproj.p, bytes, hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+  }
+  return VAQHIP_OK;
+}
+
+int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int projected, float *lut_out) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (nq < 0 || (nq > 0 && (!queries || !lut_out))) return fail(VAQHIP_EINVAL, "bad arguments");
+  if (nq == 0) return VAQHIP_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  const int ksub = 1 << ix->max_bits;
+  const size_t per_q = (size_t)ix->M * ksub;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nq, ((size_t)256 << 20) / (per_q * 4)));
+  HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
+  HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
+  HIP_TRY(ix->w_lutref.ensure((size_t)chunk * per_q * sizeof(float)));
+  hipStream_t st = ix->stream;
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int n = std::min(chunk, nq - q0);
+    HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries + (size_t)q0 * ix->D, (size_t)n * ix->D * sizeof(float),
+                           hipMemcpyHostToDevice, st));
+    const float *qp = ix->w_q.as<float>();
+    if (!projected && ix->has_eig) {
+      HIP_TRY(vaq::launch_project(qp, n, ix->D, ix->d_eig.as<float>(), ix->w_qproj.as<float>(), st));
+      qp = ix->w_qproj.as<float>();
+    }
+    HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
+                                  ix->d_cent.as<float>(), ix->lut_floats, ix->w_lut.as<float>(), st));
+    HIP_TRY(vaq::launch_lut_expand(ix->w_lut.as<float>(), n, ix->M, ix->d_sub.as<vaq::SubDesc>(),
+                                   ix->lut_floats, ksub, ix->w_lutref.as<float>(), st));
+    HIP_TRY(hipMemcpyAsync(lut_out + (size_t)q0 * per_q, ix->w_lutref.p, (size_t)n * per_q * sizeof(float),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return VAQHIP_OK;
+}
+
+int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists, const int32_t *d_label_lists,
+                             int n_lists, int nq, int k, int32_t *d_labels_out, float *d_dist_out,
+                             void *stream) {
+  if (n_lists < 0 || nq < 0 || k <= 0) return fail(VAQHIP_EINVAL, "bad sizes");
+  if (k > VAQHIP_MAX_K) return fail(VAQHIP_EUNSUPPORTED, "k=%d > %d", k, VAQHIP_MAX_K);
+  if (nq == 0) return VAQHIP_OK;
+  if ((n_lists > 0 && (!d_dist_lists || !d_label_lists)) || !d_labels_out || !d_dist_out)
+    return fail(VAQHIP_EINVAL, "null pointer");
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
+  HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, n_lists, (int64_t)nq * k, k, nq, k, 0, 1,
+                            d_labels_out, d_dist_out, static_cast<hipStream_t>(stream)));
+  return VAQHIP_OK;
+}
+
+int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out) {
+  if (!ix || !out) return fail(VAQHIP_EINVAL, "null pointer");
+  out->D = ix->D;
+  out->M = ix->M;
+  out->L = ix->L;
+  out->max_bits = ix->max_bits;
+  out->total_bits = ix->total_bits;
+  out->code_bytes = ix->layout == vaq::LAYOUT_BYTES ? ix->M : ix->W * 4;
+  out->algo_code_bytes = (ix->total_bits + 7) / 8;
+  out->lut_floats = ix->lut_floats;
+  out->N = ix->N < 0 ? 0 : ix->N;
+  out->id_base = ix->id_base;
+  out->device_id = ix->device;
+  out->layout = ix->layout;
+  return VAQHIP_OK;
+}
+
+int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
+  if (!ix || !key) return fail(VAQHIP_EINVAL, "null pointer");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  const std::string k(key);
+  if (k == "queries_per_pass") {
+    if (value != 0 && value != 1 && value != 2 && value != 4)
+      return fail(VAQHIP_EINVAL, "queries_per_pass must be 0, 1, 2 or 4");
+    ix->opt_qb = (int)value;
+  } else if (k == "slices") {
+    if (value < 0 || value > (1 << 20)) return fail(VAQHIP_EINVAL, "slices out of range");
+    ix->opt_slices = (int)value;
+  } else if (k == "timing") {
+    ix->opt_timing = value != 0;
+  } else if (k == "candidate_capacity") {
+    if (value < 0 || value > 4096) return fail(VAQHIP_EINVAL, "candidate_capacity out of range");
+    ix->opt_kcap = (int)value;
+  } else {
+    return fail(VAQHIP_EINVAL, "unknown option '%s'", key);
+  }
+  return VAQHIP_OK;
+}
+
+int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out) {
+  if (!ix || !out) return fail(VAQHIP_EINVAL, "null pointer");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (ix->ev_used > 0) {
+    DeviceGuard g(ix->device);
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < ix->ev_used; i++) {
+      hipEvent_t *ev = ix->ev.data() + (size_t)i * 5;
+      HIP_TRY(hipEventSynchronize(ev[4]));
+      for (int j = 0; j < 4; j++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
+        acc[j] += ms;
+      }
+    }
+    const double n = ix->ev_used;
+    ix->last.project_ms = (float)(acc[0] / n);
+    ix->last.lut_ms = (float)(acc[1] / n);
+    ix->last.scan_ms = (float)(acc[2] / n);
+    ix->last.merge_ms = (float)(acc[3] / n);
+    ix->last.n_searches = ix->ev_used;
+    ix->ev_used = 0;
+  }
+  *out = ix->last;
+  return VAQHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,290 @@
+"""Python mirror of the reference's `class VAQ` search interface
+(bitvecengine/VAQ.hpp:36-113) over the C ABI of include/vaqhip.h.
+
+Member names follow the reference (mBitsAlloc, mCentroidsPerSubs, mCodebook,
+mEigenVectors, mMethods ...) so harness code reads like the reference's
+drivers (examples/demo_vaq.cpp:58-345).  All compute goes through
+libvaqhip.so; nothing here has a NumPy fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class NNMethod:
+    """VAQ::NNMethod bit flags (VAQ.hpp:38-49)."""
+    Sort = 0x01
+    EA = 0x02
+    TI = 0x04
+    Fast = 0x08
+    Fast2 = 0x10
+    Fast3 = 0x20
+    Fast4 = 0x40
+    Heap = 0x80
+
+
+@dataclass
+class LabelDistVec:
+    """utils/Types.hpp:98-104: flat nq*k labels / distances."""
+    labels: np.ndarray = field(default_factory=lambda: np.empty(0, np.int32))
+    distances: np.ndarray = field(default_factory=lambda: np.empty(0, np.float32))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class VaqHip:
+    """Drop-in for the search half of `class VAQ`.
+
+    Typical use (mirrors demo_vaq.cpp:58-345)::
+
+        vaq = VaqHip()
+        vaq.parseMethodString("VAQ64m8min8max8var1,HEAP")
+        vaq.mBitsAlloc = [8] * 8
+        vaq.mCentroidsPerSubs = [...]          # K_s x L float32 each
+        vaq.mEigenVectors = E                  # D x D (real part), or None
+        vaq.mCodebook = codes                  # N x M uint16 (CodebookType)
+        ans = vaq.search(XTest, 100)           # LabelDistVec
+    """
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        # VAQ.hpp:51-55
+        self.mBitBudget = 0
+        self.mSubspaceNum = 0
+        self.mPercentVarExplained = 1.0
+        self.mMinBitsPerSubs = 0
+        self.mMaxBitsPerSubs = 0
+        self.mMethods = NNMethod.Heap
+        # VAQ.hpp:57-75
+        self.mEigenVectors: Optional[np.ndarray] = None
+        self.mCentroidsPerSubs: List[np.ndarray] = []
+        self.mBitsAlloc: List[int] = []
+        self.mCodebook: Optional[np.ndarray] = None
+        self.id_base = 0
+        self._h = C.c_void_p()
+        self._sig = None
+        self._codes_sig = None
+
+    # ------------------------------------------------------------ parsing --
+    def parseMethodString(self, methodString: str) -> None:
+        """VAQ::parseMethodString (VAQ.cpp:1189-1267).  HEAP and EA select the
+        scan on this path; the other tokens the reference accepts (SORT, TI*,
+        FAST*) are outside it and raise."""
+        for token in methodString.split(","):
+            if token.startswith("VAQ"):
+                m = re.match(r"VAQ(\d+)m(\d+)min(\d+)max(\d+)var([0-9.]+)", token)
+                if m:
+                    self.mBitBudget = int(m.group(1))
+                    self.mSubspaceNum = int(m.group(2))
+                    self.mMinBitsPerSubs = int(m.group(3))
+                    self.mMaxBitsPerSubs = int(m.group(4))
+                    self.mPercentVarExplained = float(m.group(5))
+            elif any(t in token for t in ("SORT", "HEAP", "EA", "TI", "FAST")):
+                methods = 0
+                for t in token.split("_"):
+                    if "SORT" in t:
+                        methods |= NNMethod.Sort
+                    elif "HEAP" in t:
+                        methods |= NNMethod.Heap
+                    elif "EA" in t:
+                        methods |= NNMethod.EA
+                    elif "TI" in t:
+                        methods |= NNMethod.TI
+                    elif "FAST3" in t:
+                        methods |= NNMethod.Fast3
+                    elif "FAST2" in t:
+                        methods |= NNMethod.Fast2
+                    elif "FAST" in t:
+                        methods |= NNMethod.Fast
+                unsupported = methods & ~(NNMethod.Heap | NNMethod.EA)
+                if unsupported:
+                    raise _lib.VaqHipError(-2, f"search method bits 0x{unsupported:02x} in "
+                                               f"'{token}' are outside the HEAP/EA path")
+                self.mMethods = methods
+
+    def searchMethod(self) -> int:
+        return self.mMethods
+
+    # ------------------------------------------------------- derived state --
+    @property
+    def mHighestSubs(self) -> int:
+        return len(self.mBitsAlloc)
+
+    @property
+    def mCentroidsNum(self) -> List[int]:
+        return [1 << b for b in self.mBitsAlloc]
+
+    @property
+    def mTotalDim(self) -> int:
+        return sum(c.shape[1] for c in self.mCentroidsPerSubs)
+
+    @property
+    def mSubsLen(self) -> int:
+        return self.mCentroidsPerSubs[0].shape[1]
+
+    # --------------------------------------------------------------- sync --
+    def _ensure_index(self):
+        L = _lib.load()
+        M = len(self.mBitsAlloc)
+        if M == 0 or len(self.mCentroidsPerSubs) != M:
+            raise _lib.VaqHipError(-1, "mBitsAlloc / mCentroidsPerSubs not set consistently")
+        cents = [np.ascontiguousarray(c, dtype=np.float32) for c in self.mCentroidsPerSubs]
+        for b, c in zip(self.mBitsAlloc, cents):
+            if c.ndim != 2 or c.shape[0] != (1 << b):
+                raise _lib.VaqHipError(-1, f"centroid matrix {c.shape} does not match {b} bits")
+        D = sum(c.shape[1] for c in cents)
+        eig = None
+        if self.mEigenVectors is not None:
+            eig = np.ascontiguousarray(np.real(self.mEigenVectors), dtype=np.float32)
+            if eig.shape != (D, D):
+                raise _lib.VaqHipError(-1, f"mEigenVectors {eig.shape} is not {D}x{D}")
+        sig = (tuple(self.mBitsAlloc), tuple(id(c) for c in self.mCentroidsPerSubs),
+               id(self.mEigenVectors), self.device)
+        if self._h and sig == self._sig:
+            return
+        self.close()
+        bits = (C.c_int * M)(*self.mBitsAlloc)
+        arr = (C.POINTER(C.c_float) * M)()
+        for i, c in enumerate(cents):
+            arr[i] = c.ctypes.data_as(C.POINTER(C.c_float))
+        h = C.c_void_p()
+        _lib.check(L.vaqhip_index_create(C.byref(h), D, M, bits, arr,
+                                         _ptr(eig) if eig is not None else None, self.device))
+        self._h = h
+        self._sig = sig
+        self._codes_sig = None
+
+    def _ensure_codes(self):
+        self._ensure_index()
+        if self.mCodebook is None:
+            if self._codes_sig is not None:
+                return  # the packed copy already lives on the device (host copy was dropped)
+            raise _lib.VaqHipError(-7, "mCodebook is not set")
+        sig = (id(self.mCodebook), self.id_base)
+        if sig == self._codes_sig:
+            return
+        cb = self.mCodebook
+        if hasattr(cb, "data_ptr"):  # torch tensor already on the device: N x M int16/uint16
+            if cb.dim() != 2 or cb.shape[1] != len(self.mBitsAlloc) or cb.element_size() != 2:
+                raise _lib.VaqHipError(-1, "device mCodebook must be N x M 16-bit")
+            import torch
+            st = torch.cuda.current_stream(cb.device).cuda_stream
+            _lib.check(_lib.load().vaqhip_index_set_codes_u16_device(
+                self._h, C.c_void_p(cb.data_ptr()), cb.shape[0], self.id_base, C.c_void_p(st)))
+            torch.cuda.current_stream(cb.device).synchronize()
+        else:
+            cb = np.ascontiguousarray(cb, dtype=np.uint16)
+            if cb.ndim != 2 or cb.shape[1] != len(self.mBitsAlloc):
+                raise _lib.VaqHipError(-1, f"mCodebook {cb.shape} is not N x {len(self.mBitsAlloc)}")
+            _lib.check(_lib.load().vaqhip_index_set_codes_u16(self._h, _ptr(cb), cb.shape[0],
+                                                              self.id_base))
+        self._codes_sig = sig
+
+    # ------------------------------------------------------------- search --
+    def search(self, XTest: np.ndarray, k: int, verbose: bool = False,
+               projected: bool = False) -> LabelDistVec:
+        """VAQ::search (VAQ.cpp:776-847): flat labels / squared distances,
+        ascending per query."""
+        if not (self.mMethods & (NNMethod.Heap | NNMethod.EA)):
+            raise _lib.VaqHipError(-2, "only HEAP / EA are implemented on this path")
+        self._ensure_codes()
+        X = np.ascontiguousarray(XTest, dtype=np.float32)
+        if X.ndim != 2 or X.shape[1] != self.mTotalDim:
+            raise _lib.VaqHipError(-1, f"XTest {X.shape} is not nq x {self.mTotalDim}")
+        nq = X.shape[0]
+        ret = LabelDistVec(np.empty(nq * k, np.int32), np.empty(nq * k, np.float32))
+        fn = _lib.load().vaqhip_search_projected if projected else _lib.load().vaqhip_search
+        _lib.check(fn(self._h, _ptr(X), nq, k, _ptr(ret.labels), _ptr(ret.distances)))
+        return ret
+
+    def search_device(self, d_queries, k: int, projected: bool = False):
+        """Device-resident variant: torch CUDA tensors in and out, enqueued on
+        torch's current stream (no host copies, no synchronisation)."""
+        import torch
+        self._ensure_codes()
+        q = d_queries.contiguous()
+        assert q.is_cuda and q.dtype == torch.float32 and q.shape[1] == self.mTotalDim
+        nq = q.shape[0]
+        labels = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        st = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check(_lib.load().vaqhip_search_device(
+            self._h, C.c_void_p(q.data_ptr()), nq, k, 1 if projected else 0,
+            C.c_void_p(labels.data_ptr()), C.c_void_p(dists.data_ptr()), C.c_void_p(st)))
+        return labels, dists
+
+    # -------------------------------------------------------- test hooks ---
+    def build_lut(self, XTest: np.ndarray, projected: bool = False) -> np.ndarray:
+        """CreateLUT for every query in the reference's LUTType layout:
+        returns (nq, M, ksub) with lut[q, s, c] (column-major ksub x M per query)."""
+        self._ensure_index()
+        X = np.ascontiguousarray(XTest, dtype=np.float32)
+        nq = X.shape[0]
+        ksub = 1 << max(self.mBitsAlloc)
+        out = np.empty((nq, len(self.mBitsAlloc), ksub), np.float32)
+        _lib.check(_lib.load().vaqhip_build_lut(self._h, _ptr(X), nq, 1 if projected else 0,
+                                                _ptr(out)))
+        return out
+
+    def project(self, X: np.ndarray) -> np.ndarray:
+        """VAQ::ProjectOnEigenVectors (VAQ.hpp:198-201)."""
+        self._ensure_index()
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        out = np.empty_like(X)
+        _lib.check(_lib.load().vaqhip_project(self._h, _ptr(X), X.shape[0], _ptr(out)))
+        return out
+
+    def set_option(self, key: str, value: int) -> None:
+        self._ensure_index()
+        _lib.check(_lib.load().vaqhip_set_option(self._h, key.encode(), int(value)))
+
+    def info(self) -> dict:
+        self._ensure_index()
+        inf = _lib.Info()
+        _lib.check(_lib.load().vaqhip_index_info(self._h, C.byref(inf)))
+        return {f: getattr(inf, f) for f, _ in _lib.Info._fields_}
+
+    def last_timing(self) -> dict:
+        t = _lib.Timing()
+        _lib.check(_lib.load().vaqhip_last_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _lib.Timing._fields_}
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().vaqhip_index_destroy(self._h)
+            self._h = C.c_void_p()
+            self._sig = None
+            self._codes_sig = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_topk_device(dist_lists, label_lists, k: int):
+    """Multi-GPU exchange step: [n_lists, nq, k] CUDA tensors (labels global,
+    empty slots -1 / FLT_MAX) -> per-query k smallest by (distance, label)."""
+    import torch
+    d = dist_lists.contiguous()
+    l = label_lists.contiguous()
+    n_lists, nq, kk = d.shape
+    assert kk == k and l.shape == d.shape and l.dtype == torch.int32 and d.dtype == torch.float32
+    out_l = torch.empty((nq, k), dtype=torch.int32, device=d.device)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=d.device)
+    st = torch.cuda.current_stream(d.device).cuda_stream
+    dev = d.device.index if d.device.index is not None else torch.cuda.current_device()
+    _lib.check(_lib.load().vaqhip_merge_topk_device(
+        dev, C.c_void_p(d.data_ptr()), C.c_void_p(l.data_ptr()), n_lists, nq, k,
+        C.c_void_p(out_l.data_ptr()), C.c_void_p(out_d.data_ptr()), C.c_void_p(st)))
+    return out_l, out_d
