@@ -61,6 +61,16 @@ def load():
         raise ImportError(
             f"{_LIB_PATH} is missing: build it with `python -m vaq_amd.build` "
             "(hipcc, gfx950). vaq_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 /
+    # libhsa-runtime64 under torch/lib, and a second copy (the system one this
+    # library's RUNPATH points at) cannot open the GPU once the first has.  Both
+    # carry the soname libamdhip64.so.7, so importing torch first makes the
+    # dynamic linker bind libvaqhip.so to the runtime torch already loaded.
+    # Without torch (a plain C/C++ host) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.vaqhip_index_create.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(i32),
