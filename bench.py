@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--qb", type=int, default=0, help="queries per pass (0 = library default)")
     ap.add_argument("--slices", type=int, default=0)
-    ap.add_argument("--kcap", type=int, default=0)
+    ap.add_argument("--ea", type=int, default=1, help="early abandon (two-phase scan) on/off")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -158,8 +158,7 @@ def main():
         v.set_option("queries_per_pass", args.qb)
     if args.slices:
         v.set_option("slices", args.slices)
-    if args.kcap:
-        v.set_option("candidate_capacity", args.kcap)
+    v.set_option("early_abandon", args.ea)
     info = v.info()
 
     def run_step():

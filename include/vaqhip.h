@@ -145,7 +145,11 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *   "timing"            1: record hipEvents (on the search's own stream) around
  *                       each kernel of every following search, up to 256
  *                       searches between two vaqhip_last_timing reads
- *   "candidate_capacity" 0 = auto, else per-wavefront candidate slots (power of 2) */
+ *   "early_abandon"     1 (default): two-phase scan that drops a row once a partial
+ *                       sum exceeds the query's current k-th best (the GPU form
+ *                       of VAQ::searchEarlyAbandon, VAQ.cpp:1694-1727); 0: every
+ *                       row is summed completely (VAQ::searchHeap).  Results are
+ *                       identical either way.                                 */
 int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
 
 typedef struct {

@@ -56,12 +56,13 @@ def test_golden(vaqlib, oracle, name):
         if not key.startswith("labels_k"):
             continue
         k = int(key[len("labels_k"):])
-        for qb in (1, 2, 4):
+        for qb, ea in [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0)]:
             v.set_option("queries_per_pass", qb)
+            v.set_option("early_abandon", ea)
             ans = v.search(z["X"], k)
             nq = z["X"].shape[0]
             assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k),
-                                z[key], z[f"dists_k{k}"], ad, what=f"{name} k={k} qb={qb}")
+                                z[key], z[f"dists_k{k}"], ad, what=f"{name} k={k} qb={qb} ea={ea}")
 
 
 CONFIGS = [
@@ -92,12 +93,14 @@ def test_search_matches_oracle(vaqlib, oracle, cfg):
     o_lut = np.stack([oracle.create_lut(Xp[q], c["cents"], max(bits)) for q in range(nq)])
     assert np.array_equal(lut.view(np.uint32), o_lut.view(np.uint32))
     ties = 0
-    for qb, slices in [(1, 0), (2, 0), (4, 0), (2, 1), (2, 3), (1, 7)]:
+    for qb, slices, ea in [(1, 0, 1), (2, 0, 1), (4, 0, 1), (2, 1, 1), (2, 3, 1), (1, 7, 1),
+                           (2, 0, 0), (4, 3, 0), (1, 1, 0)]:
         v.set_option("queries_per_pass", qb)
         v.set_option("slices", slices)
+        v.set_option("early_abandon", ea)
         ans = v.search(c["X"], k)
         ties += assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), o_lab, o_dis,
-                                    ad, what=f"cfg{seed} qb={qb} slices={slices}")
+                                    ad, what=f"cfg{seed} qb={qb} slices={slices} ea={ea}")
     if kw.get("integer"):
         assert ties > 0  # the boundary-tie rule was exercised
 
@@ -179,13 +182,18 @@ def test_full_size_properties(vaqlib):
     v = make_index(c)
     k = 100
     res = {}
-    for qb in (1, 2, 4):
+    for qb, ea, sl in [(1, 0, 0), (1, 1, 0), (2, 1, 0), (4, 1, 0), (2, 0, 5), (2, 1, 16), (4, 1, 61)]:
         v.set_option("queries_per_pass", qb)
+        v.set_option("early_abandon", ea)
+        v.set_option("slices", sl)
         a = v.search(c["X"], k)
-        res[qb] = (a.labels.reshape(64, k).copy(), a.distances.reshape(64, k).copy())
-    for qb in (2, 4):
-        assert np.array_equal(res[qb][0], res[1][0]) and np.array_equal(res[qb][1], res[1][1])
-    lab, dis = res[1]
+        res[(qb, ea, sl)] = (a.labels.reshape(64, k).copy(), a.distances.reshape(64, k).copy())
+    v.set_option("slices", 0)
+    v.set_option("early_abandon", 1)
+    base = res[(1, 0, 0)]
+    for key, r in res.items():
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), key
+    lab, dis = base
     assert np.all(np.diff(dis, axis=1) >= 0)
     assert lab.min() >= 0 and lab.max() < 1_000_000
     assert all(len(set(r.tolist())) == k for r in lab)

@@ -41,7 +41,11 @@ struct ScanParams {
   int lut_floats;
   int nq;
   int k;
-  int kcap;               // per-wave candidate capacity (power of two, >= k + 64)
+  int kp;                 // power of two >= k: slots of a wave's best list
+  int ccap;               // slots of a wave's candidate region
+  int qcap;               // slots of a wave's survivor queue (early abandon)
+  int ea;                 // 1: two-phase early abandon (results identical to 0)
+  unsigned *g_thr;        // [nq] shared threshold distances (float bits), preset to FLT_MAX
   int qb;                 // queries per pass (1, 2, 4)
   int n_slices;           // row slices per query batch
   int64_t slice_rows;     // rows per slice (multiple of the workgroup step)
@@ -63,12 +67,12 @@ int64_t packed_words(int64_t rows, int M, int layout, int W);
 hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64_t row_end,
                              int64_t out_row_end, int M, int layout, int W, const SubDesc *sub,
                              uint32_t *out, hipStream_t st);
-// bytes of LDS a scan workgroup needs, or 0 when the configuration is unsupported
-size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int kcap);
+// LDS geometry of a scan workgroup for top-k = k
+void scan_geometry(int layout, int M, int W, int k, int ea, int *kp, int *ccap, int *qcap);
+// bytes of LDS a scan workgroup needs
+size_t scan_lds_bytes(int layout, int M, int W, int lut_floats, int qb, int k, int ea);
 // rows one workgroup step covers (slice_rows must be a multiple of it)
 int scan_wg_step_rows(int layout, int M);
-// rows one wavefront can admit per query between two prune checks
-int scan_admit_per_step(int layout, int M);
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
 // in_final != 0: inputs use the API's -1 / FLT_MAX convention for empty slots
 // candidate i of list l of query q sits at l*list_stride + q*query_stride + i

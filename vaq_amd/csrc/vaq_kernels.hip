@@ -232,101 +232,156 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 }
 
 // ---------------------------------------------------------------------------
-// Bitonic sort of P (power of two) (distance, id) pairs in LDS, ascending by
-// (distance, id).  WG = false: one wavefront, no barriers (LDS is in-order per
-// wave); WG = true: the whole workgroup with __syncthreads.
+// Bitonic networks on (distance, id) pairs in LDS, ascending by (distance, id).
+// WG = false: one wavefront, no barriers (LDS is in-order per wave);
+// WG = true : the whole workgroup with __syncthreads.
 // ---------------------------------------------------------------------------
 template <bool WG>
-__device__ __forceinline__ void bitonic_sort(float *d, int *id, int P, int tid, int nthreads) {
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int p = tid; p < (P >> 1); p += nthreads) {
-        int i = 2 * p - (p & (stride - 1));
-        int j = i + stride;
-        bool asc = (i & size) == 0;
-        float di = d[i], dj = d[j];
-        int ii = id[i], ij = id[j];
-        bool gt = pair_less(dj, ij, di, ii);
-        if (gt == asc) {
-          d[i] = dj; d[j] = di;
-          id[i] = ij; id[j] = ii;
-        }
-      }
-      if (WG) __syncthreads();
-      else wave_lds_sync();
+__device__ __forceinline__ void bitonic_stage(float *d, int *id, int P, int size, int stride,
+                                              int tid, int nthreads) {
+  for (int p = tid; p < (P >> 1); p += nthreads) {
+    const int i = 2 * p - (p & (stride - 1));
+    const int j = i + stride;
+    const bool asc = (i & size) == 0;
+    const float di = d[i], dj = d[j];
+    const int ii = id[i], ij = id[j];
+    const bool gt = pair_less(dj, ij, di, ii);
+    if (gt == asc) {
+      d[i] = dj; d[j] = di;
+      id[i] = ij; id[j] = ii;
     }
   }
+  if (WG) __syncthreads();
+  else wave_lds_sync();
+}
+
+// full sort of P (power of two) entries
+template <bool WG>
+__device__ __forceinline__ void bitonic_sort(float *d, int *id, int P, int tid, int nthreads) {
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1)
+      bitonic_stage<WG>(d, id, P, size, stride, tid, nthreads);
+}
+
+// P entries forming a bitonic sequence -> ascending
+template <bool WG>
+__device__ __forceinline__ void bitonic_merge(float *d, int *id, int P, int tid, int nthreads) {
+  for (int stride = P >> 1; stride > 0; stride >>= 1)
+    bitonic_stage<WG>(d, id, P, P << 1, stride, tid, nthreads);
 }
 
 // ---------------------------------------------------------------------------
 // Per-wavefront running k-min of VAQ::searchHeap (VAQ.cpp:1750-1753 with
-// utils/Heap.hpp:115-169): a candidate buffer of kcap slots in LDS, private to
-// the wave, plus the wave-uniform admission threshold (thr_d, thr_id) = the
-// current k-th best.  A row is admitted iff it is strictly below the
-// threshold in (distance, id) order -- the reference admits iff
-// heap_top > dist, i.e. strictly better than its current k-th.  Initial
-// threshold FLT_MAX reproduces heap_heapify's neutral (utils/Heap.hpp:211-235):
-// a distance >= FLT_MAX is never admitted.
-// Invariant: before a step that can admit up to A rows, cnt <= kcap - A.
+// utils/Heap.hpp:115-169).  LDS, private to the wave, per query:
+//   [0, kp)        the wave's current best list, ascending, sentinel-padded
+//                  (kp = power of two >= k)
+//   [kp, kp+ccap)  rows admitted since the last prune (unsorted)
+// plus the wave-uniform admission threshold (thr_d, thr_id).  A row is
+// admitted iff it is strictly below the threshold in (distance, id) order --
+// the reference admits iff heap_top > dist, i.e. strictly better than its
+// current k-th.  The initial threshold FLT_MAX reproduces heap_heapify's
+// neutral element (utils/Heap.hpp:211-235): a distance >= FLT_MAX is never
+// admitted.  The threshold is an upper bound on the final k-th best of the
+// query, so it may be tightened from ANY source (other waves, other
+// workgroups): rows at or above it can never be in the result.
 // ---------------------------------------------------------------------------
 struct WaveSel {
   float *d;
   int *id;
-  int cnt;      // wave-uniform
+  int nbest;    // wave-uniform: real entries in the best list (<= k)
+  int ncand;    // wave-uniform: entries in the candidate region
   float thr_d;  // wave-uniform
   int thr_id;   // wave-uniform
 };
 
-__device__ __forceinline__ void wavesel_init(WaveSel &s, float *d, int *id) {
+__device__ __forceinline__ void wavesel_init(WaveSel &s, float *d, int *id, int kp, int lane) {
   s.d = d;
   s.id = id;
-  s.cnt = 0;
+  s.nbest = 0;
+  s.ncand = 0;
   s.thr_d = FLT_MAX;
   s.thr_id = INT_MIN;
+  for (int i = lane; i < kp; i += 64) {
+    d[i] = INFINITY;
+    id[i] = ID_SENTINEL;
+  }
 }
 
-__device__ __forceinline__ void wavesel_admit(WaveSel &s, float dist, int rid, bool valid, int lane) {
-  const bool pass = valid && pair_less(dist, rid, s.thr_d, s.thr_id);
+// adopt a threshold distance published by someone else (ties at t stay admissible)
+__device__ __forceinline__ void wavesel_adopt(WaveSel &s, float t) {
+  if (t < s.thr_d) {
+    s.thr_d = t;
+    s.thr_id = INT_MAX;
+  }
+}
+
+__device__ __forceinline__ void wavesel_admit(WaveSel &s, float dist, int rid, bool ok, int kp) {
+  const bool pass = ok && pair_less(dist, rid, s.thr_d, s.thr_id);
   const unsigned long long m = __ballot(pass);
   if (m != 0ull) {
-    const int pos = s.cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int pos = kp + s.ncand +
+                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     if (pass) {
       s.d[pos] = dist;
       s.id[pos] = rid;
     }
-    s.cnt += __popcll(m);
+    s.ncand += __popcll(m);
   }
-  (void)lane;
 }
 
-// sort the buffer, keep the k best, refresh the threshold
-__device__ __forceinline__ void wavesel_prune(WaveSel &s, int k, int lane) {
-  int P = 2;
-  while (P < s.cnt) P <<= 1;
-  for (int i = s.cnt + lane; i < P; i += 64) {
-    s.d[i] = INFINITY;
-    s.id[i] = ID_SENTINEL;
+// Fold the candidate region into the best list:
+//   sort the candidates (padded to cp = power of two >= ncand), take
+//   min(best[kp-1-j], cand[j]) -- the kp smallest of the union, as a bitonic
+//   sequence -- and bitonic-merge it back to ascending.  Returns true when the
+//   threshold moved.
+__device__ __forceinline__ bool wavesel_prune(WaveSel &s, int k, int kp, int lane) {
+  float *cd = s.d + kp;
+  int *ci = s.id + kp;
+  int cp = 2;
+  while (cp < s.ncand) cp <<= 1;
+  for (int i = s.ncand + lane; i < cp; i += 64) {
+    cd[i] = INFINITY;
+    ci[i] = ID_SENTINEL;
   }
   wave_lds_sync();
-  bitonic_sort<false>(s.d, s.id, P, lane, 64);
-  if (s.cnt >= k) {
-    s.cnt = k;
-    s.thr_d = __builtin_bit_cast(
-        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s.d[k - 1])));
-    s.thr_id = __builtin_amdgcn_readfirstlane(s.id[k - 1]);
+  bitonic_sort<false>(cd, ci, cp, lane, 64);
+  const int n = cp < kp ? cp : kp;  // candidates beyond the kp best of them cannot matter
+  for (int j = lane; j < n; j += 64) {
+    const int i = kp - 1 - j;
+    const float db = s.d[i], dc = cd[j];
+    const int ib = s.id[i], ic = ci[j];
+    if (pair_less(dc, ic, db, ib)) {
+      s.d[i] = dc;
+      s.id[i] = ic;
+    }
   }
+  wave_lds_sync();
+  bitonic_merge<false>(s.d, s.id, kp, lane, 64);
+  int nb = s.nbest + s.ncand;
+  s.nbest = nb < k ? nb : k;
+  s.ncand = 0;
+  bool moved = false;
+  if (s.nbest == k) {
+    const float td = __builtin_bit_cast(
+        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s.d[k - 1])));
+    const int ti = __builtin_amdgcn_readfirstlane(s.id[k - 1]);
+    if (pair_less(td, ti, s.thr_d, s.thr_id)) {
+      s.thr_d = td;
+      s.thr_id = ti;
+      moved = true;
+    }
+  }
+  return moved;
 }
 
-// final: sort what is left and write the wave's k best (sentinel-padded)
-__device__ __forceinline__ void wavesel_flush(WaveSel &s, int k, int lane, float *out_d,
+// final: fold what is left and write the wave's k best (sentinel-padded)
+__device__ __forceinline__ void wavesel_flush(WaveSel &s, int k, int kp, int lane, float *out_d,
                                               int *out_id) {
-  wavesel_prune(s, k, lane);
-  const int c = s.cnt;
+  if (s.ncand > 0) wavesel_prune(s, k, kp, lane);
   for (int i = lane; i < k; i += 64) {
-    const bool ok = i < c;
-    out_d[i] = ok ? s.d[i] : INFINITY;
-    out_id[i] = ok ? s.id[i] : ID_SENTINEL;
+    out_d[i] = s.d[i];
+    out_id[i] = s.id[i];
   }
 }
 
@@ -338,7 +393,141 @@ __device__ __forceinline__ void wavesel_flush(WaveSel &s, int k, int lane, float
 __device__ __forceinline__ int xcd_virtual_id(int b, int G) { return (b & 7) * (G >> 3) + (b >> 3); }
 
 constexpr int SCAN_THREADS = SCAN_WAVES * 64;
-constexpr int PREFETCH = 2;  // items loaded ahead of the one being processed
+constexpr int PREFETCH = 2;        // items loaded ahead of the one being processed
+constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the survivor test
+constexpr int THR_LOCAL_EVERY = 4; // steps between reads of the workgroup threshold
+constexpr int THR_GLOBAL_EVERY = 64;
+
+__device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// Shared scaffolding of the two scan kernels: LDS carve-up, threshold
+// exchange, result write-out.
+template <int QB> struct ScanCtx {
+  typedef typename LutVec<QB>::T LT;
+  LT *lut;
+  unsigned *wg_thr;  // [QB] workgroup-wide threshold distance (float bits; distances are >= 0,
+                     // so unsigned order == float order)
+  WaveSel sel[QB];
+  int qi[QB];
+  int *q_id;         // survivor queue (wave-private): row id
+  float *q_p;        // [QB][qcap]: sum of the row's first group of four subspaces
+  int qcap, qcnt;
+  int lane, wave;
+  int k, kp;
+  bool multi_slice;
+  unsigned *g_thr;
+
+  __device__ __forceinline__ void setup(unsigned char *smem, const ScanParams &p, int lut_entries,
+                                        int qbatch, int tid) {
+    lane = tid & 63;
+    wave = tid >> 6;
+    k = p.k;
+    kp = p.kp;
+    qcap = p.qcap;
+    qcnt = 0;
+    multi_slice = p.n_slices > 1;
+    g_thr = p.g_thr;
+    lut = reinterpret_cast<LT *>(smem);
+    size_t off = ((size_t)lut_entries * sizeof(LT) + 15) & ~(size_t)15;
+    wg_thr = reinterpret_cast<unsigned *>(smem + off);
+    off += 16;
+    const size_t sel_bytes = (size_t)(p.kp + p.ccap) * 8;
+    const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
+    unsigned char *wb = smem + off + (size_t)wave * (QB * sel_bytes + q_bytes);
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      const int x = qbatch * QB + q;
+      qi[q] = x < p.nq ? x : p.nq - 1;
+      float *d = reinterpret_cast<float *>(wb + (size_t)q * sel_bytes);
+      wavesel_init(sel[q], d, reinterpret_cast<int *>(d + p.kp + p.ccap), p.kp, lane);
+    }
+    unsigned char *qb = wb + QB * sel_bytes;
+    q_id = reinterpret_cast<int *>(qb);
+    q_p = reinterpret_cast<float *>(qb + (size_t)p.qcap * 4);
+#pragma unroll
+    for (int q = 0; q < QB; q++)
+      if (tid == q) wg_thr[q] = multi_slice ? g_thr[qi[q]] : float_to_bits(FLT_MAX);
+    for (int e = tid; e < lut_entries; e += SCAN_THREADS) {
+      LT val;
+#pragma unroll
+      for (int q = 0; q < QB; q++) lv_set<QB>(val, q, p.lut[(size_t)qi[q] * p.lut_floats + e]);
+      lut[e] = val;
+    }
+  }
+
+  // after a prune moved the threshold of query q: publish its distance
+  __device__ __forceinline__ void publish(int q) {
+    if (lane == 0) {
+      const unsigned b = float_to_bits(sel[q].thr_d);
+      atomicMin(&wg_thr[q], b);
+      if (multi_slice) atomicMin(&g_thr[qi[q]], b);
+    }
+  }
+
+  __device__ __forceinline__ void refresh(int64_t st) {
+    if ((st & (THR_LOCAL_EVERY - 1)) != 0) return;
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      unsigned t = __hip_atomic_load(&wg_thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (multi_slice && (st & (THR_GLOBAL_EVERY - 1)) == 0) {
+        const unsigned g = __hip_atomic_load(&g_thr[qi[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g < t) {
+          t = g;
+          if (lane == 0) atomicMin(&wg_thr[q], g);
+        }
+      }
+      t = __builtin_amdgcn_readfirstlane(t);
+      wavesel_adopt(sel[q], bits_to_float(t));
+    }
+  }
+
+  __device__ __forceinline__ void prune_if_full(int limit) {
+#pragma unroll
+    for (int q = 0; q < QB; q++)
+      if (sel[q].ncand > limit)
+        if (wavesel_prune(sel[q], k, kp, lane)) publish(q);
+  }
+
+  // true when the partial sums rule the row out for every query of the batch:
+  // all LUT entries are >= 0 and fp32 addition is monotone, so a partial sum
+  // is a lower bound of the final distance (the reference's early abandon,
+  // VAQ.cpp:1708, uses the same bound at group granularity).
+  __device__ __forceinline__ bool survives(const float (&part)[QB]) const {
+    bool a = false;
+#pragma unroll
+    for (int q = 0; q < QB; q++) a = a || !(part[q] > sel[q].thr_d);
+    return a;
+  }
+
+  // compact the lanes with `alive` set into the survivor queue
+  __device__ __forceinline__ void push(bool alive, int rid, const float (&acc)[QB]) {
+    const unsigned long long m = __ballot(alive);
+    if (m != 0ull) {
+      const int pos = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      if (alive) {
+        q_id[pos] = rid;
+#pragma unroll
+        for (int q = 0; q < QB; q++) q_p[q * qcap + pos] = acc[q];
+      }
+      qcnt += __popcll(m);
+    }
+  }
+
+  __device__ __forceinline__ void write_out(const ScanParams &p, int slice, int qbatch) {
+    const int nslots = p.n_slices * SCAN_WAVES;
+    const int slot = slice * SCAN_WAVES + wave;
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      const int x = qbatch * QB + q;
+      if (x < p.nq) {
+        const size_t o = ((size_t)x * nslots + slot) * k;
+        wavesel_flush(sel[q], k, kp, lane, p.part_d + o, p.part_id + o);
+      }
+    }
+  }
+};
 
 // ---- code-stream item: what one lane consumes per step --------------------
 // LAYOUT_BYTES, M subspaces of 8 bits: an item is max(16, M) bytes = 16/M rows
@@ -363,20 +552,35 @@ template <int M> struct BytesItem {
 };
 
 // ---------------------------------------------------------------------------
-// VAQ::searchHeap for 8-bit codes (VAQ.cpp:1729-1758).  Per row:
-//   dist = 0; for each group of 4 subspaces: dism = ((l0 + l1) + l2) + l3;
-//   dist += dism   (:1737-1748), plain fp32 adds.
+// VAQ::searchHeap / searchEarlyAbandon for 8-bit codes (VAQ.cpp:1694-1758).
+// Per row:  dist = 0; for each group of 4 subspaces:
+//             dism = l0; dism += l1; dism += l2; dism += l3; dist += dism
+// (:1737-1748), plain fp32 adds.
 // A workgroup stages the LUTs of QB queries in LDS, interleaved per entry
 // ([entry][query], so one ds_read_b32/b64/b128 serves all QB queries), and
 // its four wavefronts stream the workgroup's row slice with coalesced 16-byte
 // loads (wave w takes every 4th KiB), two items prefetched ahead.
+//
+// EA = true (default) is the GPU form of searchEarlyAbandon:
+//   A   every lane: dism = l0 + l1 (the two highest-variance subspaces after
+//       PCA); a row whose partial sum already exceeds the threshold of every
+//       query of the batch is dead
+//   A2  live lanes only (EXEC-masked): dism += l2; dism += l3 -> the first
+//       group's sum; test again
+//   Q   rows still alive are compacted (row id + group sum) into a
+//       wave-private LDS queue
+//   B   whenever 64 survivors are queued, one per lane: re-read the row's code
+//       words (L2-resident, just streamed), add the remaining groups in the
+//       reference's order, abandoning after each, and admit to the k-min.
+// Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
-template <int M, int QB>
+template <int M, int QB, bool EA>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
+  constexpr int WPR = Item::WPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int nqb = (p.nq + QB - 1) / QB;
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
@@ -384,36 +588,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
   const int slice = v / nqb;
   const int qbatch = v - slice * nqb;
 
-  LT *lut = reinterpret_cast<LT *>(smem);
-  constexpr int LUT_ENTRIES = M * 256;
-  int qi[QB];
-#pragma unroll
-  for (int q = 0; q < QB; q++) {
-    int x = qbatch * QB + q;
-    qi[q] = x < p.nq ? x : p.nq - 1;
-  }
-  for (int e = tid; e < LUT_ENTRIES; e += SCAN_THREADS) {
-    LT val;
-#pragma unroll
-    for (int q = 0; q < QB; q++) lv_set<QB>(val, q, p.lut[(size_t)qi[q] * p.lut_floats + e]);
-    lut[e] = val;
-  }
-
-  const int k = p.k, kcap = p.kcap;
-  WaveSel sel[QB];
-  {
-    unsigned char *base = smem + (size_t)LUT_ENTRIES * sizeof(LT) + (size_t)wave * QB * kcap * 8;
-#pragma unroll
-    for (int q = 0; q < QB; q++) {
-      float *d = reinterpret_cast<float *>(base + (size_t)q * kcap * 8);
-      wavesel_init(sel[q], d, reinterpret_cast<int *>(d + kcap));
-    }
-  }
+  ScanCtx<QB> cx;
+  cx.setup(smem, p, M * 256, qbatch, tid);
+  const LT *lut = cx.lut;
+  const int lane = cx.lane, wave = cx.wave;
   __syncthreads();
 
   // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the workgroup
-  // step and the code buffer is padded to n_slices * slice_rows rows, so every
-  // load is in bounds; rows >= n_rows are masked out.
+  // step and the code buffer is padded to a multiple of it, so every load is
+  // in bounds; rows >= n_rows are masked out.
   const int64_t r0 = (int64_t)slice * p.slice_rows;
   int64_t r1 = r0 + p.slice_rows;
   if (r1 > p.n_rows) r1 = p.n_rows;
@@ -422,7 +605,54 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
   const int64_t n_steps = (r1 > r0) ? ((r1 - r0) + (int64_t)STEP_ITEMS * Item::ROWS - 1) /
                                           ((int64_t)STEP_ITEMS * Item::ROWS)
                                     : 0;
-  const int admit_limit = kcap - 64 * Item::ROWS;
+  const int admit_limit = p.ccap - (EA ? 64 : 64 * Item::ROWS);
+  const uint32_t *__restrict__ codes = p.codes;
+
+  // subspaces [first, last) of group g: dism = l0; dism += l1; dism += l2; dism += l3
+  auto group_sum = [&](const uint32_t c4, const int g, const int first, const int last,
+                       float (&dism)[QB]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j < first || j >= last) continue;
+      const LT l = lut[(g * 4 + j) * 256 + ((c4 >> (8 * j)) & 0xffu)];
+#pragma unroll
+      for (int q = 0; q < QB; q++) dism[q] = (j == 0) ? lv_get<QB>(l, q) : dism[q] + lv_get<QB>(l, q);
+    }
+  };
+
+  // groups 1.. of a row whose first group's sum is in acc[]; then admission
+  auto finish = [&](const uint32_t (&cw)[WPR], float (&acc)[QB], const int rid, bool alive) {
+#pragma unroll
+    for (int g = 1; g < WPR; g++) {
+      if (!EA || alive) {
+        float dism[QB];
+        group_sum(cw[g], g, 0, 4, dism);
+#pragma unroll
+        for (int q = 0; q < QB; q++) acc[q] = acc[q] + dism[q];  // dist += dism
+        if (EA) alive = cx.survives(acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], rid, alive, cx.kp);
+  };
+
+  // phase B: the top n (<= 64) queue entries, one per lane
+  auto drain = [&](const int n) {
+    const int base = cx.qcnt - n;
+    const bool ok = lane < n;
+    const int slot = base + (ok ? lane : 0);
+    const int rid = cx.q_id[slot];
+    float acc[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) acc[q] = cx.q_p[q * cx.qcap + slot];
+    cx.qcnt = base;
+    uint32_t cw[WPR];
+    cw[0] = 0u;
+#pragma unroll
+    for (int i = 1; i < WPR; i++) cw[i] = codes[(int64_t)rid * WPR + i];
+    finish(cw, acc, rid, ok);
+    cx.prune_if_full(admit_limit);
+  };
 
   Item pf[PREFETCH];
 #pragma unroll
@@ -435,54 +665,52 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
     for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
     if (st + PREFETCH < n_steps)
       pf[PREFETCH - 1].load(p.codes, item0 + (st + PREFETCH) * STEP_ITEMS);
+    cx.refresh(st);
 
     const int64_t row0 = (item0 + st * STEP_ITEMS) * Item::ROWS;
+    if (!EA) {
 #pragma unroll
-    for (int r = 0; r < Item::ROWS; r++) {
-      float acc[QB];
+      for (int r = 0; r < Item::ROWS; r++) {
+        uint32_t cw[WPR];
 #pragma unroll
-      for (int g = 0; g < Item::WPR; g++) {
-        const uint32_t c4 = cur.word(r, g);
-        const LT l0 = lut[(g * 4 + 0) * 256 + (c4 & 0xffu)];
-        const LT l1 = lut[(g * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)];
-        const LT l2 = lut[(g * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)];
-        const LT l3 = lut[(g * 4 + 3) * 256 + (c4 >> 24)];
-#pragma unroll
-        for (int q = 0; q < QB; q++) {
-          float dism = lv_get<QB>(l0, q);
-          dism += lv_get<QB>(l1, q);
-          dism += lv_get<QB>(l2, q);
-          dism += lv_get<QB>(l3, q);
-          acc[q] = (g == 0) ? dism : acc[q] + dism;  // dist = 0; dist += dism
-        }
+        for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
+        float acc[QB];
+        group_sum(cw[0], 0, 0, 4, acc);  // dist = 0; dist += dism
+        finish(cw, acc, (int)(row0 + r), row0 + r < r1);
       }
-      const int64_t row = row0 + r;
-      const bool valid = row < r1;
+      cx.prune_if_full(admit_limit);
+    } else {
+      // A: every row of the item, all lanes
+      float part[Item::ROWS][QB];
+      bool alive[Item::ROWS];
 #pragma unroll
-      for (int q = 0; q < QB; q++) wavesel_admit(sel[q], acc[q], (int)row, valid, lane);
+      for (int r = 0; r < Item::ROWS; r++) group_sum(cur.word(r, 0), 0, 0, PHASE_A_SUBS, part[r]);
+#pragma unroll
+      for (int r = 0; r < Item::ROWS; r++) alive[r] = (row0 + r < r1) && cx.survives(part[r]);
+      // A2 + Q per row
+#pragma unroll
+      for (int r = 0; r < Item::ROWS; r++) {
+        bool live = alive[r];
+        if (live) {
+          group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
+          live = cx.survives(part[r]);
+        }
+        cx.push(live, (int)(row0 + r), part[r]);
+      }
+      while (cx.qcnt >= 64) drain(64);
     }
-#pragma unroll
-    for (int q = 0; q < QB; q++)
-      if (sel[q].cnt > admit_limit) wavesel_prune(sel[q], k, lane);
   }
-
-  const int nslots = p.n_slices * SCAN_WAVES;
-  const int slot = slice * SCAN_WAVES + wave;
-#pragma unroll
-  for (int q = 0; q < QB; q++) {
-    const int x = qbatch * QB + q;
-    if (x < p.nq) {
-      const size_t o = ((size_t)x * nslots + slot) * k;
-      wavesel_flush(sel[q], k, lane, p.part_d + o, p.part_id + o);
-    }
-  }
+  if (EA && cx.qcnt > 0) drain(cx.qcnt);
+  cx.write_out(p, slice, qbatch);
 }
 
 // ---------------------------------------------------------------------------
-// VAQ::searchHeap for arbitrary 1..15-bit codes (the variance-aware
-// non-uniform allocation).  Same arithmetic; codes are bit-packed
-// (LAYOUT_BITS: planar 64-row tiles), LUT packed with per-subspace offsets.
-// W = dwords per row; one row per lane per step.
+// VAQ::searchHeap / searchEarlyAbandon for arbitrary 1..15-bit codes (the
+// variance-aware non-uniform allocation).  Same arithmetic and the same
+// phases as scan_bytes_kernel; codes are bit-packed (LAYOUT_BITS: planar
+// 64-row tiles), the LUT is packed with per-subspace offsets.  W = dwords per
+// row; one row per lane per step.  The first group's four fields span at most
+// 60 bits, i.e. dwords 0 and 1.
 // ---------------------------------------------------------------------------
 template <int W> struct BitsItem {
   uint32_t w[W];
@@ -493,12 +721,12 @@ template <int W> struct BitsItem {
   }
 };
 
-template <int W, int QB>
+template <int W, int QB, bool EA>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int nqb = (p.nq + QB - 1) / QB;
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
@@ -506,42 +734,70 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
   const int slice = v / nqb;
   const int qbatch = v - slice * nqb;
 
-  LT *lut = reinterpret_cast<LT *>(smem);
-  const int lut_entries = p.lut_floats;
-  int qi[QB];
-#pragma unroll
-  for (int q = 0; q < QB; q++) {
-    int x = qbatch * QB + q;
-    qi[q] = x < p.nq ? x : p.nq - 1;
-  }
-  for (int e = tid; e < lut_entries; e += SCAN_THREADS) {
-    LT val;
-#pragma unroll
-    for (int q = 0; q < QB; q++) lv_set<QB>(val, q, p.lut[(size_t)qi[q] * p.lut_floats + e]);
-    lut[e] = val;
-  }
-  const int k = p.k, kcap = p.kcap;
-  WaveSel sel[QB];
-  {
-    const size_t lut_bytes = ((size_t)lut_entries * sizeof(LT) + 15) & ~(size_t)15;
-    unsigned char *base = smem + lut_bytes + (size_t)wave * QB * kcap * 8;
-#pragma unroll
-    for (int q = 0; q < QB; q++) {
-      float *d = reinterpret_cast<float *>(base + (size_t)q * kcap * 8);
-      wavesel_init(sel[q], d, reinterpret_cast<int *>(d + kcap));
-    }
-  }
+  ScanCtx<QB> cx;
+  cx.setup(smem, p, p.lut_floats, qbatch, tid);
+  const LT *lut = cx.lut;
+  const int lane = cx.lane, wave = cx.wave;
   __syncthreads();
 
   const int64_t r0 = (int64_t)slice * p.slice_rows;
   int64_t r1 = r0 + p.slice_rows;
   if (r1 > p.n_rows) r1 = p.n_rows;
   const int64_t tile0 = r0 / TILE_ROWS + wave;
-  const int64_t n_steps =
-      (r1 > r0) ? ((r1 - r0) + SCAN_THREADS - 1) / SCAN_THREADS : 0;
-  const int admit_limit = kcap - 64;
+  const int64_t n_steps = (r1 > r0) ? ((r1 - r0) + SCAN_THREADS - 1) / SCAN_THREADS : 0;
+  const int admit_limit = p.ccap - 64;
+  const int M = p.M;
   const SubDesc *__restrict__ sub = p.sub;
   const int *__restrict__ first_sub = p.first_sub;
+  const uint32_t *__restrict__ codes = p.codes;
+
+  // one more subspace of the reference's chain: dism = l0; dism += l1..l3; dist += dism
+  auto chain = [&](const int s, const LT l, float (&acc)[QB], float (&dism)[QB]) {
+    const int ph = s & 3;
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      const float x = lv_get<QB>(l, q);
+      dism[q] = (ph == 0) ? x : dism[q] + x;
+      if (ph == 3) acc[q] = (s == 3) ? dism[q] : acc[q] + dism[q];
+    }
+  };
+
+  // phase B: the top n (<= 64) queue entries, one per lane; groups 1.. are
+  // extracted from the row's code words, re-read from the planar tiles
+  auto drain = [&](const int n) {
+    const int base = cx.qcnt - n;
+    const bool ok = lane < n;
+    const int slot = base + (ok ? lane : 0);
+    const int rid = cx.q_id[slot];
+    float acc[QB], dism[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      acc[q] = cx.q_p[q * cx.qcap + slot];
+      dism[q] = 0.0f;
+    }
+    cx.qcnt = base;
+    const uint32_t *rp = codes + (int64_t)(rid / TILE_ROWS) * (TILE_ROWS * W) + (rid % TILE_ROWS);
+    bool alive = ok;
+    int cur_word = -1;
+    uint32_t lo = 0, hi = 0;
+    for (int s = 4; s < M; s++) {
+      const SubDesc sd = sub[s];
+      if (sd.word != cur_word) {
+        cur_word = sd.word;
+        lo = rp[cur_word * TILE_ROWS];
+        hi = (cur_word + 1 < W) ? rp[(cur_word + 1) * TILE_ROWS] : 0u;
+      }
+      if (alive) {
+        const uint32_t c =
+            __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
+        chain(s, lut[sd.lut_off + c], acc, dism);
+        if ((s & 3) == 3) alive = cx.survives(acc);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], rid, alive, cx.kp);
+    cx.prune_if_full(admit_limit);
+  };
 
   Item pf[PREFETCH];
 #pragma unroll
@@ -554,66 +810,83 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
     for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
     if (st + PREFETCH < n_steps)
       pf[PREFETCH - 1].load(p.codes, tile0 + (st + PREFETCH) * SCAN_WAVES, lane);
+    cx.refresh(st);
 
+    const int64_t row = (tile0 + st * SCAN_WAVES) * TILE_ROWS + lane;
+    const bool valid = row < r1;
     float acc[QB], dism[QB];
 #pragma unroll
     for (int q = 0; q < QB; q++) { acc[q] = 0.0f; dism[q] = 0.0f; }
-    int s = 0;
+    if (EA) {
+      const uint32_t w0 = cur.w[0];
+      const uint32_t w1 = W > 1 ? cur.w[W > 1 ? 1 : 0] : 0u;
+      // A: fields 0 and 1 (always inside dword 0)
+      const SubDesc s0 = sub[0], s1 = sub[1];
+      chain(0, lut[s0.lut_off + (w0 & (unsigned)(s0.ncent - 1))], acc, dism);
+      chain(1, lut[s1.lut_off + ((w0 >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
+      bool live = valid && cx.survives(dism);
+      if (live) {
+        // A2: fields 2 and 3 (dwords 0..1) complete the first group
+        const SubDesc s2 = sub[2], s3 = sub[3];
+        const uint32_t c2 = (s2.word == 0 ? __builtin_amdgcn_alignbit(w1, w0, (unsigned)s2.shift)
+                                          : (w1 >> s2.shift)) & (unsigned)(s2.ncent - 1);
+        const uint32_t c3 = (s3.word == 0 ? __builtin_amdgcn_alignbit(w1, w0, (unsigned)s3.shift)
+                                          : (w1 >> s3.shift)) & (unsigned)(s3.ncent - 1);
+        chain(2, lut[s2.lut_off + c2], acc, dism);
+        chain(3, lut[s3.lut_off + c3], acc, dism);
+        live = cx.survives(acc);
+      }
+      cx.push(live, (int)row, acc);
+      while (cx.qcnt >= 64) drain(64);
+    } else {
+      int s = 0;
 #pragma unroll
-    for (int wi = 0; wi < W; wi++) {
-      const uint32_t lo = cur.w[wi];
-      const uint32_t hi = (wi + 1 < W) ? cur.w[wi + 1 < W ? wi + 1 : wi] : 0u;
-      const int s_end = first_sub[wi + 1];
-      for (; s < s_end; s++) {
-        const SubDesc sd = sub[s];
-        const uint32_t c =
-            __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
-        const LT l = lut[sd.lut_off + c];
-        const int ph = s & 3;
-#pragma unroll
-        for (int q = 0; q < QB; q++) {
-          const float x = lv_get<QB>(l, q);
-          dism[q] = (ph == 0) ? x : dism[q] + x;              // dism = l0; dism += l1..l3
-          if (ph == 3) acc[q] = (s == 3) ? dism[q] : acc[q] + dism[q];  // dist += dism
+      for (int wi = 0; wi < W; wi++) {
+        const uint32_t lo = cur.w[wi];
+        const uint32_t hi = (wi + 1 < W) ? cur.w[wi + 1 < W ? wi + 1 : wi] : 0u;
+        const int s_end = first_sub[wi + 1];
+        for (; s < s_end; s++) {
+          const SubDesc sd = sub[s];
+          const uint32_t c =
+              __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
+          chain(s, lut[sd.lut_off + c], acc, dism);
         }
       }
-    }
-    const int64_t row = (tile0 + st * SCAN_WAVES) * TILE_ROWS + lane;
-    const bool valid = row < r1;
 #pragma unroll
-    for (int q = 0; q < QB; q++) {
-      wavesel_admit(sel[q], acc[q], (int)row, valid, lane);
-      if (sel[q].cnt > admit_limit) wavesel_prune(sel[q], k, lane);
+      for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], (int)row, valid, cx.kp);
+      cx.prune_if_full(admit_limit);
     }
   }
-
-  const int nslots = p.n_slices * SCAN_WAVES;
-  const int slot = slice * SCAN_WAVES + wave;
-#pragma unroll
-  for (int q = 0; q < QB; q++) {
-    const int x = qbatch * QB + q;
-    if (x < p.nq) {
-      const size_t o = ((size_t)x * nslots + slot) * k;
-      wavesel_flush(sel[q], k, lane, p.part_d + o, p.part_id + o);
-    }
-  }
+  if (EA && cx.qcnt > 0) drain(cx.qcnt);
+  cx.write_out(p, slice, qbatch);
 }
 
-size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int kcap) {
-  size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
-  lut = (lut + 15) & ~(size_t)15;
-  return lut + (size_t)SCAN_WAVES * qb * kcap * 8;
-}
-
+// ---- launch geometry shared with the host --------------------------------
 int scan_wg_step_rows(int layout, int M) {
   if (layout == LAYOUT_BYTES) return SCAN_THREADS * (M < 16 ? 16 / M : 1);
   return SCAN_THREADS;
 }
 
-// candidate rows one wave can admit per query between two prune checks
-int scan_admit_per_step(int layout, int M) {
-  if (layout == LAYOUT_BYTES) return 64 * (M < 16 ? 16 / M : 1);
-  return 64;
+// rows one wave can push into a candidate region between two prune checks
+static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
+
+void scan_geometry(int layout, int M, int W, int k, int ea, int *kp, int *ccap, int *qcap) {
+  int p2 = 1;
+  while (p2 < k) p2 <<= 1;
+  *kp = p2;
+  const int rpi = rows_per_item(layout, M);
+  *ccap = ea ? 128 : 128 * rpi;
+  *qcap = ea ? 64 + 64 * rpi : 0;
+  (void)W;
+}
+
+size_t scan_lds_bytes(int layout, int M, int W, int lut_floats, int qb, int k, int ea) {
+  int kp, ccap, qcap;
+  scan_geometry(layout, M, W, k, ea, &kp, &ccap, &qcap);
+  size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
+  lut = (lut + 15) & ~(size_t)15;
+  const size_t per_wave = (size_t)qb * (kp + ccap) * 8 + (size_t)qcap * 4 * (1 + qb);
+  return lut + 16 + (size_t)SCAN_WAVES * per_wave;
 }
 
 template <typename K>
@@ -626,12 +899,21 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
   return hipGetLastError();
 }
 
-#define VAQ_DISPATCH_QB(KERNEL, A)                                                   \
-  switch (p.qb) {                                                                    \
-  case 1: return launch_scan_kernel(KERNEL<A, 1>, p, lds, grid, st);                 \
-  case 2: return launch_scan_kernel(KERNEL<A, 2>, p, lds, grid, st);                 \
-  case 4: return launch_scan_kernel(KERNEL<A, 4>, p, lds, grid, st);                 \
-  default: return hipErrorInvalidValue;                                              \
+#define VAQ_DISPATCH_QB(KERNEL, A)                                                        \
+  if (p.ea) {                                                                             \
+    switch (p.qb) {                                                                       \
+    case 1: return launch_scan_kernel(KERNEL<A, 1, true>, p, lds, grid, st);              \
+    case 2: return launch_scan_kernel(KERNEL<A, 2, true>, p, lds, grid, st);              \
+    case 4: return launch_scan_kernel(KERNEL<A, 4, true>, p, lds, grid, st);              \
+    default: return hipErrorInvalidValue;                                                 \
+    }                                                                                     \
+  } else {                                                                                \
+    switch (p.qb) {                                                                       \
+    case 1: return launch_scan_kernel(KERNEL<A, 1, false>, p, lds, grid, st);             \
+    case 2: return launch_scan_kernel(KERNEL<A, 2, false>, p, lds, grid, st);             \
+    case 4: return launch_scan_kernel(KERNEL<A, 4, false>, p, lds, grid, st);             \
+    default: return hipErrorInvalidValue;                                                 \
+    }                                                                                     \
   }
 
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
@@ -640,7 +922,7 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
-  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.kcap);
+  const size_t lds = scan_lds_bytes(p.layout, p.M, p.W, p.lut_floats, p.qb, p.k, p.ea);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes_kernel, 8)

@@ -59,12 +59,6 @@ struct DevBuf {
   template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
-int next_pow2(int x) {
-  int p = 1;
-  while (p < x) p <<= 1;
-  return p;
-}
-
 constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
@@ -82,10 +76,10 @@ struct vaqhip_index {
   bool has_eig = false;
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
-  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref;
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_kcap = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 5, created on first use
@@ -109,33 +103,29 @@ struct DeviceGuard {
 };
 
 struct Plan {
-  int qb, kcap, n_slices;
+  int qb, ea, kp, ccap, qcap, n_slices;
   int64_t slice_rows;
   size_t lds;
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
-  const int admit = vaq::scan_admit_per_step(ix->layout, ix->M);
-  const int kcap_min = next_pow2(k + admit);
-  int kcap = ix->opt_kcap > 0 ? std::max(next_pow2(ix->opt_kcap), kcap_min)
-                              : next_pow2(k + admit + std::max(64, k));
+  const int ea = ix->opt_ea ? 1 : 0;
   int qb = ix->opt_qb > 0 ? ix->opt_qb : 2;
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
-  if (qb == 3) qb = 2;
-  // fit LDS: first shrink the candidate buffers, then the query batch
+  // fit LDS by shrinking the query batch
   for (;;) {
-    size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, kcap);
+    size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->W, ix->lut_floats, qb, k, ea);
     if (lds <= LDS_LIMIT) break;
-    if (kcap > kcap_min) kcap >>= 1;
-    else if (qb > 1) qb >>= 1;
+    if (qb > 1) qb >>= 1;
     else
       return fail(VAQHIP_EUNSUPPORTED,
                   "lookup tables of %d floats plus top-%d buffers need %zu B of LDS (> %zu)",
                   ix->lut_floats, k, lds, LDS_LIMIT);
   }
   pl->qb = qb;
-  pl->kcap = kcap;
-  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, kcap);
+  pl->ea = ea;
+  vaq::scan_geometry(ix->layout, ix->M, ix->W, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->W, ix->lut_floats, qb, k, ea);
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const int64_t N = ix->N;
   const int nqb = (nq + qb - 1) / qb;
@@ -194,6 +184,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   const int nslots = pl.n_slices * vaq::SCAN_WAVES;
   HIP_TRY(ix->w_part_d.ensure((size_t)chunk * nslots * k * sizeof(float)));
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
+  HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
 
   if (timing && nq > chunk)
     return fail(VAQHIP_EUNSUPPORTED, "timing supports at most %d queries per call", QUERY_CHUNK);
@@ -223,13 +214,19 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.lut_floats = ix->lut_floats;
     sp.nq = n;
     sp.k = k;
-    sp.kcap = pl.kcap;
+    sp.kp = pl.kp;
+    sp.ccap = pl.ccap;
+    sp.qcap = pl.qcap;
+    sp.ea = pl.ea;
+    sp.g_thr = ix->w_thr.as<unsigned>();
     sp.qb = pl.qb;
     sp.n_slices = pl.n_slices;
     sp.slice_rows = pl.slice_rows;
     sp.part_d = ix->w_part_d.as<float>();
     sp.part_id = ix->w_part_id.as<int>();
     int grid = 0;
+    // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));
     const int lists = ix->N > 0 ? nslots : 0;
@@ -362,7 +359,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_labels,
-                      &ix->w_dist, &ix->w_stage, &ix->w_lutref})
+                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr})
       b->release();
   }
   delete ix;
@@ -570,9 +567,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     ix->opt_slices = (int)value;
   } else if (k == "timing") {
     ix->opt_timing = value != 0;
-  } else if (k == "candidate_capacity") {
-    if (value < 0 || value > 4096) return fail(VAQHIP_EINVAL, "candidate_capacity out of range");
-    ix->opt_kcap = (int)value;
+  } else if (k == "early_abandon") {
+    ix->opt_ea = value != 0;
   } else {
     return fail(VAQHIP_EINVAL, "unknown option '%s'", key);
   }
