@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--qb", type=int, default=0, help="queries per pass (0 = library default)")
     ap.add_argument("--slices", type=int, default=0)
     ap.add_argument("--ea", type=int, default=1, help="early abandon (two-phase scan) on/off")
+    ap.add_argument("--nwaves", type=int, default=0, help="wavefronts per scan workgroup (0 = auto)")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -159,6 +160,8 @@ def main():
     if args.slices:
         v.set_option("slices", args.slices)
     v.set_option("early_abandon", args.ea)
+    if args.nwaves:
+        v.set_option("waves_per_workgroup", args.nwaves)
     info = v.info()
 
     def run_step():

@@ -24,8 +24,8 @@ enum Layout { LAYOUT_BYTES = 0, LAYOUT_BITS = 1 };
 
 // rows per planar tile of the bit-packed layout (one wavefront step)
 constexpr int TILE_ROWS = 64;
-// wavefronts per scan workgroup
-constexpr int SCAN_WAVES = 4;
+// most wavefronts a scan workgroup may have (the host picks 4, 8 or 16)
+constexpr int SCAN_MAX_WAVES = 16;
 // sentinel id of an empty candidate slot (sorts after every real id)
 constexpr int ID_SENTINEL = 0x7fffffff;
 
@@ -41,15 +41,16 @@ struct ScanParams {
   int lut_floats;
   int nq;
   int k;
-  int kp;                 // power of two >= k: slots of a wave's best list
-  int ccap;               // slots of a wave's candidate region
+  int kp;                 // power of two >= k: slots of a workgroup's best list (per query)
+  int ccap;               // slots of its candidate region
   int qcap;               // slots of a wave's survivor queue (early abandon)
+  int nwaves;             // wavefronts per workgroup
   int ea;                 // 1: two-phase early abandon (results identical to 0)
   unsigned *g_thr;        // [nq] shared threshold distances (float bits), preset to FLT_MAX
   int qb;                 // queries per pass (1, 2, 4)
   int n_slices;           // row slices per query batch
   int64_t slice_rows;     // rows per slice (multiple of the workgroup step)
-  float *part_d;          // [nq][n_slices*SCAN_WAVES][k]
+  float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
 
@@ -68,10 +69,11 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
                              int64_t out_row_end, int M, int layout, int W, const SubDesc *sub,
                              uint32_t *out, hipStream_t st);
 // LDS geometry of a scan workgroup for top-k = k
-void scan_geometry(int layout, int M, int W, int k, int ea, int *kp, int *ccap, int *qcap);
-// bytes of LDS a scan workgroup needs
-size_t scan_lds_bytes(int layout, int M, int W, int lut_floats, int qb, int k, int ea);
-// rows one workgroup step covers (slice_rows must be a multiple of it)
+void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap);
+// bytes of LDS a scan workgroup of `nwaves` wavefronts needs
+size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves);
+// rows one step of the LARGEST workgroup covers: slice_rows and the code
+// buffer's padding must be multiples of it
 int scan_wg_step_rows(int layout, int M);
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
 // in_final != 0: inputs use the API's -1 / FLT_MAX convention for empty slots

@@ -271,76 +271,74 @@ __device__ __forceinline__ void bitonic_merge(float *d, int *id, int P, int tid,
 }
 
 // ---------------------------------------------------------------------------
-// Per-wavefront running k-min of VAQ::searchHeap (VAQ.cpp:1750-1753 with
-// utils/Heap.hpp:115-169).  LDS, private to the wave, per query:
-//   [0, kp)        the wave's current best list, ascending, sentinel-padded
+// Running k-min of VAQ::searchHeap (VAQ.cpp:1750-1753 with
+// utils/Heap.hpp:115-169), ONE per (workgroup, query), in LDS:
+//   header   lock, ncand, nbest, thr_d (float bits), thr_id
+//   [0, kp)        current best list, ascending, sentinel-padded
 //                  (kp = power of two >= k)
-//   [kp, kp+ccap)  rows admitted since the last prune (unsorted)
-// plus the wave-uniform admission threshold (thr_d, thr_id).  A row is
-// admitted iff it is strictly below the threshold in (distance, id) order --
-// the reference admits iff heap_top > dist, i.e. strictly better than its
-// current k-th.  The initial threshold FLT_MAX reproduces heap_heapify's
-// neutral element (utils/Heap.hpp:211-235): a distance >= FLT_MAX is never
-// admitted.  The threshold is an upper bound on the final k-th best of the
-// query, so it may be tightened from ANY source (other waves, other
-// workgroups): rows at or above it can never be in the result.
+//   [kp, kp+ccap)  rows admitted since the last fold (unsorted)
+// A row is admitted iff it is strictly below the threshold (thr_d, thr_id) in
+// (distance, id) order -- the reference admits iff heap_top > dist, i.e.
+// strictly better than its current k-th.  The initial threshold FLT_MAX
+// reproduces heap_heapify's neutral element (utils/Heap.hpp:211-235): a
+// distance >= FLT_MAX is never admitted.  The threshold is an upper bound on
+// the final k-th best of the query, so it may be tightened from ANY source
+// (other workgroups): rows at or above it can never be in the result.
+//
+// Admissions are rare (about k*ln(rows/k) per query over a whole scan), so
+// they are serialised by a workgroup lock: a wave that has candidates takes
+// the lock, re-tests them against the exact threshold, folds the candidate
+// region into the best list when it would overflow, appends, and releases.
+// Waves only READ the threshold word while scanning.
 // ---------------------------------------------------------------------------
-struct WaveSel {
+enum { SEL_LOCK = 0, SEL_NCAND = 1, SEL_NBEST = 2, SEL_THR_D = 3, SEL_THR_ID = 4, SEL_HDR_WORDS = 8 };
+
+struct SelView {
+  unsigned *hdr;
   float *d;
   int *id;
-  int nbest;    // wave-uniform: real entries in the best list (<= k)
-  int ncand;    // wave-uniform: entries in the candidate region
-  float thr_d;  // wave-uniform
-  int thr_id;   // wave-uniform
 };
 
-__device__ __forceinline__ void wavesel_init(WaveSel &s, float *d, int *id, int kp, int lane) {
-  s.d = d;
-  s.id = id;
-  s.nbest = 0;
-  s.ncand = 0;
-  s.thr_d = FLT_MAX;
-  s.thr_id = INT_MIN;
-  for (int i = lane; i < kp; i += 64) {
-    d[i] = INFINITY;
-    id[i] = ID_SENTINEL;
-  }
+__device__ __forceinline__ size_t sel_bytes(int kp, int ccap) {
+  return (size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8;
 }
 
-// adopt a threshold distance published by someone else (ties at t stay admissible)
-__device__ __forceinline__ void wavesel_adopt(WaveSel &s, float t) {
-  if (t < s.thr_d) {
-    s.thr_d = t;
-    s.thr_id = INT_MAX;
-  }
+__device__ __forceinline__ SelView sel_view(unsigned char *base, int kp, int ccap) {
+  SelView v;
+  v.hdr = reinterpret_cast<unsigned *>(base);
+  v.d = reinterpret_cast<float *>(base + SEL_HDR_WORDS * 4);
+  v.id = reinterpret_cast<int *>(v.d + kp + ccap);
+  return v;
 }
 
-__device__ __forceinline__ void wavesel_admit(WaveSel &s, float dist, int rid, bool ok, int kp) {
-  const bool pass = ok && pair_less(dist, rid, s.thr_d, s.thr_id);
-  const unsigned long long m = __ballot(pass);
-  if (m != 0ull) {
-    const int pos = kp + s.ncand +
-                    __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                              __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (pass) {
-      s.d[pos] = dist;
-      s.id[pos] = rid;
-    }
-    s.ncand += __popcll(m);
+__device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
+
+__device__ __forceinline__ void sel_lock(const SelView &v, int lane) {
+  if (lane == 0) {
+    while (atomicCAS(&v.hdr[SEL_LOCK], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Fold the candidate region into the best list:
-//   sort the candidates (padded to cp = power of two >= ncand), take
-//   min(best[kp-1-j], cand[j]) -- the kp smallest of the union, as a bitonic
-//   sequence -- and bitonic-merge it back to ascending.  Returns true when the
-//   threshold moved.
-__device__ __forceinline__ bool wavesel_prune(WaveSel &s, int k, int kp, int lane) {
-  float *cd = s.d + kp;
-  int *ci = s.id + kp;
+__device__ __forceinline__ void sel_unlock(const SelView &v, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&v.hdr[SEL_LOCK], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Fold the candidate region into the best list (caller holds the lock, one
+// wave): sort the candidates (padded to cp = power of two >= ncand), take
+// min(best[kp-1-j], cand[j]) -- the kp smallest of the union, as a bitonic
+// sequence -- and bitonic-merge it back to ascending.  Updates nbest, ncand
+// and the threshold.  Returns true when the threshold moved.
+__device__ __forceinline__ bool sel_fold(const SelView &v, int k, int kp, int lane) {
+  const int ncand = (int)v.hdr[SEL_NCAND];
+  if (ncand == 0) return false;
+  float *cd = v.d + kp;
+  int *ci = v.id + kp;
   int cp = 2;
-  while (cp < s.ncand) cp <<= 1;
-  for (int i = s.ncand + lane; i < cp; i += 64) {
+  while (cp < ncand) cp <<= 1;
+  for (int i = ncand + lane; i < cp; i += 64) {
     cd[i] = INFINITY;
     ci[i] = ID_SENTINEL;
   }
@@ -349,40 +347,35 @@ __device__ __forceinline__ bool wavesel_prune(WaveSel &s, int k, int kp, int lan
   const int n = cp < kp ? cp : kp;  // candidates beyond the kp best of them cannot matter
   for (int j = lane; j < n; j += 64) {
     const int i = kp - 1 - j;
-    const float db = s.d[i], dc = cd[j];
-    const int ib = s.id[i], ic = ci[j];
+    const float db = v.d[i], dc = cd[j];
+    const int ib = v.id[i], ic = ci[j];
     if (pair_less(dc, ic, db, ib)) {
-      s.d[i] = dc;
-      s.id[i] = ic;
+      v.d[i] = dc;
+      v.id[i] = ic;
     }
   }
   wave_lds_sync();
-  bitonic_merge<false>(s.d, s.id, kp, lane, 64);
-  int nb = s.nbest + s.ncand;
-  s.nbest = nb < k ? nb : k;
-  s.ncand = 0;
+  bitonic_merge<false>(v.d, v.id, kp, lane, 64);
+  int nb = (int)v.hdr[SEL_NBEST] + ncand;
+  nb = nb < k ? nb : k;
   bool moved = false;
-  if (s.nbest == k) {
-    const float td = __builtin_bit_cast(
-        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s.d[k - 1])));
-    const int ti = __builtin_amdgcn_readfirstlane(s.id[k - 1]);
-    if (pair_less(td, ti, s.thr_d, s.thr_id)) {
-      s.thr_d = td;
-      s.thr_id = ti;
-      moved = true;
+  if (nb == k) {
+    const float td = v.d[k - 1];
+    const int ti = v.id[k - 1];
+    const float od = bits_to_float(v.hdr[SEL_THR_D]);
+    const int oi = (int)v.hdr[SEL_THR_ID];
+    moved = pair_less(td, ti, od, oi);
+    if (moved && lane == 0) {
+      v.hdr[SEL_THR_D] = float_to_bits(td);
+      v.hdr[SEL_THR_ID] = (unsigned)ti;
     }
   }
-  return moved;
-}
-
-// final: fold what is left and write the wave's k best (sentinel-padded)
-__device__ __forceinline__ void wavesel_flush(WaveSel &s, int k, int kp, int lane, float *out_d,
-                                              int *out_id) {
-  if (s.ncand > 0) wavesel_prune(s, k, kp, lane);
-  for (int i = lane; i < k; i += 64) {
-    out_d[i] = s.d[i];
-    out_id[i] = s.id[i];
+  if (lane == 0) {
+    v.hdr[SEL_NBEST] = (unsigned)nb;
+    v.hdr[SEL_NCAND] = 0u;
   }
+  wave_lds_sync();
+  return moved;
 }
 
 // XCD-aware workgroup -> (slice, query batch) mapping.  Workgroups are dealt
@@ -392,63 +385,74 @@ __device__ __forceinline__ void wavesel_flush(WaveSel &s, int k, int kp, int lan
 // only: any placement is correct.
 __device__ __forceinline__ int xcd_virtual_id(int b, int G) { return (b & 7) * (G >> 3) + (b >> 3); }
 
-constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 constexpr int PREFETCH = 2;        // items loaded ahead of the one being processed
-constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the survivor test
-constexpr int THR_LOCAL_EVERY = 4; // steps between reads of the workgroup threshold
+constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
+constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
 constexpr int THR_GLOBAL_EVERY = 64;
 
-__device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
-
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
-// exchange, result write-out.
+// exchange, survivor queue, admission, result write-out.
+// LDS: [LUT][QB x selection state][per wave: survivor queue]
 template <int QB> struct ScanCtx {
   typedef typename LutVec<QB>::T LT;
   LT *lut;
-  unsigned *wg_thr;  // [QB] workgroup-wide threshold distance (float bits; distances are >= 0,
-                     // so unsigned order == float order)
-  WaveSel sel[QB];
+  SelView sel[QB];
+  float thr_d[QB];   // wave-uniform cached copy of each query's threshold distance (>= exact)
   int qi[QB];
   int *q_id;         // survivor queue (wave-private): row id
   float *q_p;        // [QB][qcap]: sum of the row's first group of four subspaces
   int qcap, qcnt;
-  int lane, wave;
-  int k, kp;
+  int lane, wave, nwaves;
+  int k, kp, ccap;
   bool multi_slice;
   unsigned *g_thr;
 
   __device__ __forceinline__ void setup(unsigned char *smem, const ScanParams &p, int lut_entries,
-                                        int qbatch, int tid) {
+                                        int qbatch, int tid, int nthreads) {
     lane = tid & 63;
     wave = tid >> 6;
+    nwaves = nthreads >> 6;
     k = p.k;
     kp = p.kp;
+    ccap = p.ccap;
     qcap = p.qcap;
     qcnt = 0;
     multi_slice = p.n_slices > 1;
     g_thr = p.g_thr;
     lut = reinterpret_cast<LT *>(smem);
     size_t off = ((size_t)lut_entries * sizeof(LT) + 15) & ~(size_t)15;
-    wg_thr = reinterpret_cast<unsigned *>(smem + off);
-    off += 16;
-    const size_t sel_bytes = (size_t)(p.kp + p.ccap) * 8;
-    const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
-    unsigned char *wb = smem + off + (size_t)wave * (QB * sel_bytes + q_bytes);
+    const size_t sb = (sel_bytes(p.kp, p.ccap) + 15) & ~(size_t)15;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       const int x = qbatch * QB + q;
       qi[q] = x < p.nq ? x : p.nq - 1;
-      float *d = reinterpret_cast<float *>(wb + (size_t)q * sel_bytes);
-      wavesel_init(sel[q], d, reinterpret_cast<int *>(d + p.kp + p.ccap), p.kp, lane);
+      sel[q] = sel_view(smem + off + (size_t)q * sb, p.kp, p.ccap);
+      thr_d[q] = FLT_MAX;
+      for (int i = tid; i < p.kp; i += nthreads) {
+        sel[q].d[i] = INFINITY;
+        sel[q].id[i] = ID_SENTINEL;
+      }
+      if (tid == q) {
+        unsigned td = float_to_bits(FLT_MAX);
+        int ti = INT_MIN;
+        if (multi_slice) {
+          const unsigned g = __hip_atomic_load(&g_thr[qi[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (g < td) { td = g; ti = INT_MAX; }
+        }
+        sel[q].hdr[SEL_LOCK] = 0u;
+        sel[q].hdr[SEL_NCAND] = 0u;
+        sel[q].hdr[SEL_NBEST] = 0u;
+        sel[q].hdr[SEL_THR_D] = td;
+        sel[q].hdr[SEL_THR_ID] = (unsigned)ti;
+      }
     }
-    unsigned char *qb = wb + QB * sel_bytes;
+    off += QB * sb;
+    const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
+    unsigned char *qb = smem + off + (size_t)wave * q_bytes;
     q_id = reinterpret_cast<int *>(qb);
     q_p = reinterpret_cast<float *>(qb + (size_t)p.qcap * 4);
-#pragma unroll
-    for (int q = 0; q < QB; q++)
-      if (tid == q) wg_thr[q] = multi_slice ? g_thr[qi[q]] : float_to_bits(FLT_MAX);
-    for (int e = tid; e < lut_entries; e += SCAN_THREADS) {
+    for (int e = tid; e < lut_entries; e += nthreads) {
       LT val;
 #pragma unroll
       for (int q = 0; q < QB; q++) lv_set<QB>(val, q, p.lut[(size_t)qi[q] * p.lut_floats + e]);
@@ -456,48 +460,79 @@ template <int QB> struct ScanCtx {
     }
   }
 
-  // after a prune moved the threshold of query q: publish its distance
-  __device__ __forceinline__ void publish(int q) {
-    if (lane == 0) {
-      const unsigned b = float_to_bits(sel[q].thr_d);
-      atomicMin(&wg_thr[q], b);
-      if (multi_slice) atomicMin(&g_thr[qi[q]], b);
-    }
-  }
-
+  // re-read the workgroup thresholds; now and then pull in what other
+  // workgroups scanning other slices of the same queries have published
   __device__ __forceinline__ void refresh(int64_t st) {
     if ((st & (THR_LOCAL_EVERY - 1)) != 0) return;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
-      unsigned t = __hip_atomic_load(&wg_thr[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (multi_slice && (st & (THR_GLOBAL_EVERY - 1)) == 0) {
+      unsigned t = __hip_atomic_load(&sel[q].hdr[SEL_THR_D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (multi_slice && wave == 0 && (st & (THR_GLOBAL_EVERY - 1)) == 0) {
         const unsigned g = __hip_atomic_load(&g_thr[qi[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g < t) {
+          sel_lock(sel[q], lane);
+          if (g < sel[q].hdr[SEL_THR_D] && lane == 0) {
+            sel[q].hdr[SEL_THR_D] = g;
+            sel[q].hdr[SEL_THR_ID] = (unsigned)INT_MAX;  // ties at g stay admissible
+          }
+          sel_unlock(sel[q], lane);
           t = g;
-          if (lane == 0) atomicMin(&wg_thr[q], g);
         }
       }
-      t = __builtin_amdgcn_readfirstlane(t);
-      wavesel_adopt(sel[q], bits_to_float(t));
+      thr_d[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)t));
     }
   }
 
-  __device__ __forceinline__ void prune_if_full(int limit) {
-#pragma unroll
-    for (int q = 0; q < QB; q++)
-      if (sel[q].ncand > limit)
-        if (wavesel_prune(sel[q], k, kp, lane)) publish(q);
-  }
-
-  // true when the partial sums rule the row out for every query of the batch:
-  // all LUT entries are >= 0 and fp32 addition is monotone, so a partial sum
-  // is a lower bound of the final distance (the reference's early abandon,
-  // VAQ.cpp:1708, uses the same bound at group granularity).
+  // true unless the partial sums rule the row out for every query of the
+  // batch: all LUT entries are >= 0 and fp32 addition is monotone, so a
+  // partial sum is a lower bound of the final distance (the reference's early
+  // abandon, VAQ.cpp:1708, uses the same bound at group granularity).
   __device__ __forceinline__ bool survives(const float (&part)[QB]) const {
     bool a = false;
 #pragma unroll
-    for (int q = 0; q < QB; q++) a = a || !(part[q] > sel[q].thr_d);
+    for (int q = 0; q < QB; q++) a = a || !(part[q] > thr_d[q]);
     return a;
+  }
+
+  // final distances of up to 64 rows (one per lane): admit those strictly
+  // below the query's threshold
+  __device__ __forceinline__ void admit(const float (&dist)[QB], int rid, bool ok) {
+#pragma unroll
+    for (int q = 0; q < QB; q++) {
+      const float dq = dist[q];
+      // cheap pre-test against the cached (never tighter than exact) threshold
+      if (__ballot(ok && !(dq > thr_d[q])) == 0ull) continue;
+      const SelView &v = sel[q];
+      sel_lock(v, lane);
+      float td = bits_to_float(v.hdr[SEL_THR_D]);
+      int ti = (int)v.hdr[SEL_THR_ID];
+      bool pass = ok && pair_less(dq, rid, td, ti);
+      unsigned long long m = __ballot(pass);
+      if (m != 0ull) {
+        int ncand = (int)v.hdr[SEL_NCAND];
+        if (ncand + __popcll(m) > ccap) {
+          if (sel_fold(v, k, kp, lane)) {
+            td = bits_to_float(v.hdr[SEL_THR_D]);
+            ti = (int)v.hdr[SEL_THR_ID];
+            if (multi_slice && lane == 0) atomicMin(&g_thr[qi[q]], float_to_bits(td));
+            pass = pass && pair_less(dq, rid, td, ti);
+            m = __ballot(pass);
+          }
+          ncand = 0;
+        }
+        if (m != 0ull) {
+          const int pos = kp + ncand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (pass) {
+            v.d[pos] = dq;
+            v.id[pos] = rid;
+          }
+          if (lane == 0) v.hdr[SEL_NCAND] = (unsigned)(ncand + __popcll(m));
+        }
+      }
+      sel_unlock(v, lane);
+      thr_d[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(td)));
+    }
   }
 
   // compact the lanes with `alive` set into the survivor queue
@@ -515,15 +550,21 @@ template <int QB> struct ScanCtx {
     }
   }
 
+  // after every wave is done: wave q folds query q's leftovers and writes the
+  // workgroup's k best (sentinel-padded) for the merge kernel
   __device__ __forceinline__ void write_out(const ScanParams &p, int slice, int qbatch) {
-    const int nslots = p.n_slices * SCAN_WAVES;
-    const int slot = slice * SCAN_WAVES + wave;
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       const int x = qbatch * QB + q;
-      if (x < p.nq) {
-        const size_t o = ((size_t)x * nslots + slot) * k;
-        wavesel_flush(sel[q], k, kp, lane, p.part_d + o, p.part_id + o);
+      if (wave == (q % nwaves) && x < p.nq) {
+        if (sel_fold(sel[q], k, kp, lane) && multi_slice && lane == 0)
+          atomicMin(&g_thr[qi[q]], sel[q].hdr[SEL_THR_D]);
+        const size_t o = ((size_t)x * p.n_slices + slice) * k;
+        for (int i = lane; i < k; i += 64) {
+          p.part_d[o + i] = sel[q].d[i];
+          p.part_id[o + i] = sel[q].id[i];
+        }
       }
     }
   }
@@ -575,12 +616,12 @@ template <int M> struct BytesItem {
 // Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
 template <int M, int QB, bool EA>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
   constexpr int WPR = Item::WPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   const int nqb = (p.nq + QB - 1) / QB;
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
@@ -589,23 +630,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
   const int qbatch = v - slice * nqb;
 
   ScanCtx<QB> cx;
-  cx.setup(smem, p, M * 256, qbatch, tid);
+  cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave;
   __syncthreads();
 
-  // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the workgroup
-  // step and the code buffer is padded to a multiple of it, so every load is
-  // in bounds; rows >= n_rows are masked out.
-  const int64_t r0 = (int64_t)slice * p.slice_rows;
-  int64_t r1 = r0 + p.slice_rows;
-  if (r1 > p.n_rows) r1 = p.n_rows;
-  constexpr int STEP_ITEMS = SCAN_THREADS;  // items per workgroup step
-  const int64_t item0 = r0 / Item::ROWS + (int64_t)wave * 64 + lane;
-  const int64_t n_steps = (r1 > r0) ? ((r1 - r0) + (int64_t)STEP_ITEMS * Item::ROWS - 1) /
-                                          ((int64_t)STEP_ITEMS * Item::ROWS)
-                                    : 0;
-  const int admit_limit = p.ccap - (EA ? 64 : 64 * Item::ROWS);
+  // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the largest
+  // workgroup step and the code buffer is padded to a multiple of it, so every
+  // load is in bounds; rows >= n_rows are masked out.
+  const int r0 = (int)((int64_t)slice * p.slice_rows);
+  const int64_t r1l = (int64_t)r0 + p.slice_rows;
+  const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
+  const int step_items = nthreads;  // items per workgroup step
+  const int64_t item0 = r0 / Item::ROWS + wave * 64 + lane;
+  const int step_rows = step_items * Item::ROWS;
+  const int n_steps = (r1 > r0) ? (r1 - r0 + step_rows - 1) / step_rows : 0;
   const uint32_t *__restrict__ codes = p.codes;
 
   // subspaces [first, last) of group g: dism = l0; dism += l1; dism += l2; dism += l3
@@ -632,8 +671,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
         if (EA) alive = cx.survives(acc);
       }
     }
-#pragma unroll
-    for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], rid, alive, cx.kp);
+    cx.admit(acc, rid, alive);
   };
 
   // phase B: the top n (<= 64) queue entries, one per lane
@@ -651,23 +689,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
 #pragma unroll
     for (int i = 1; i < WPR; i++) cw[i] = codes[(int64_t)rid * WPR + i];
     finish(cw, acc, rid, ok);
-    cx.prune_if_full(admit_limit);
   };
 
   Item pf[PREFETCH];
 #pragma unroll
   for (int i = 0; i < PREFETCH; i++)
-    if (i < n_steps) pf[i].load(p.codes, item0 + (int64_t)i * STEP_ITEMS);
+    if (i < n_steps) pf[i].load(p.codes, item0 + (int64_t)i * step_items);
 
-  for (int64_t st = 0; st < n_steps; st++) {
+  for (int st = 0; st < n_steps; st++) {
     const Item cur = pf[0];
 #pragma unroll
     for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
     if (st + PREFETCH < n_steps)
-      pf[PREFETCH - 1].load(p.codes, item0 + (st + PREFETCH) * STEP_ITEMS);
+      pf[PREFETCH - 1].load(p.codes, item0 + (int64_t)(st + PREFETCH) * step_items);
     cx.refresh(st);
 
-    const int64_t row0 = (item0 + st * STEP_ITEMS) * Item::ROWS;
+    const int row0 = (int)(item0 + (int64_t)st * step_items) * Item::ROWS;
     if (!EA) {
 #pragma unroll
       for (int r = 0; r < Item::ROWS; r++) {
@@ -676,9 +713,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
         for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
         float acc[QB];
         group_sum(cw[0], 0, 0, 4, acc);  // dist = 0; dist += dism
-        finish(cw, acc, (int)(row0 + r), row0 + r < r1);
+        finish(cw, acc, row0 + r, row0 + r < r1);
       }
-      cx.prune_if_full(admit_limit);
     } else {
       // A: every row of the item, all lanes
       float part[Item::ROWS][QB];
@@ -695,7 +731,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bytes_kernel(ScanParams p) 
           group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
           live = cx.survives(part[r]);
         }
-        cx.push(live, (int)(row0 + r), part[r]);
+        cx.push(live, row0 + r, part[r]);
       }
       while (cx.qcnt >= 64) drain(64);
     }
@@ -722,11 +758,11 @@ template <int W> struct BitsItem {
 };
 
 template <int W, int QB, bool EA>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
   const int nqb = (p.nq + QB - 1) / QB;
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
@@ -735,17 +771,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
   const int qbatch = v - slice * nqb;
 
   ScanCtx<QB> cx;
-  cx.setup(smem, p, p.lut_floats, qbatch, tid);
+  cx.setup(smem, p, p.lut_floats, qbatch, tid, nthreads);
   const LT *lut = cx.lut;
-  const int lane = cx.lane, wave = cx.wave;
+  const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
   __syncthreads();
 
-  const int64_t r0 = (int64_t)slice * p.slice_rows;
-  int64_t r1 = r0 + p.slice_rows;
-  if (r1 > p.n_rows) r1 = p.n_rows;
+  const int r0 = (int)((int64_t)slice * p.slice_rows);
+  const int64_t r1l = (int64_t)r0 + p.slice_rows;
+  const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
   const int64_t tile0 = r0 / TILE_ROWS + wave;
-  const int64_t n_steps = (r1 > r0) ? ((r1 - r0) + SCAN_THREADS - 1) / SCAN_THREADS : 0;
-  const int admit_limit = p.ccap - 64;
+  const int n_steps = (r1 > r0) ? (r1 - r0 + nthreads - 1) / nthreads : 0;
   const int M = p.M;
   const SubDesc *__restrict__ sub = p.sub;
   const int *__restrict__ first_sub = p.first_sub;
@@ -794,25 +829,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
         if ((s & 3) == 3) alive = cx.survives(acc);
       }
     }
-#pragma unroll
-    for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], rid, alive, cx.kp);
-    cx.prune_if_full(admit_limit);
+    cx.admit(acc, rid, alive);
   };
 
   Item pf[PREFETCH];
 #pragma unroll
   for (int i = 0; i < PREFETCH; i++)
-    if (i < n_steps) pf[i].load(p.codes, tile0 + (int64_t)i * SCAN_WAVES, lane);
+    if (i < n_steps) pf[i].load(p.codes, tile0 + (int64_t)i * nwaves, lane);
 
-  for (int64_t st = 0; st < n_steps; st++) {
+  for (int st = 0; st < n_steps; st++) {
     const Item cur = pf[0];
 #pragma unroll
     for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
     if (st + PREFETCH < n_steps)
-      pf[PREFETCH - 1].load(p.codes, tile0 + (st + PREFETCH) * SCAN_WAVES, lane);
+      pf[PREFETCH - 1].load(p.codes, tile0 + (int64_t)(st + PREFETCH) * nwaves, lane);
     cx.refresh(st);
 
-    const int64_t row = (tile0 + st * SCAN_WAVES) * TILE_ROWS + lane;
+    const int row = (int)(tile0 + (int64_t)st * nwaves) * TILE_ROWS + lane;
     const bool valid = row < r1;
     float acc[QB], dism[QB];
 #pragma unroll
@@ -836,7 +869,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
         chain(3, lut[s3.lut_off + c3], acc, dism);
         live = cx.survives(acc);
       }
-      cx.push(live, (int)row, acc);
+      cx.push(live, row, acc);
       while (cx.qcnt >= 64) drain(64);
     } else {
       int s = 0;
@@ -852,9 +885,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
           chain(s, lut[sd.lut_off + c], acc, dism);
         }
       }
-#pragma unroll
-      for (int q = 0; q < QB; q++) wavesel_admit(cx.sel[q], acc[q], (int)row, valid, cx.kp);
-      cx.prune_if_full(admit_limit);
+      cx.admit(acc, row, valid);
     }
   }
   if (EA && cx.qcnt > 0) drain(cx.qcnt);
@@ -862,31 +893,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_bits_kernel(ScanParams p) {
 }
 
 // ---- launch geometry shared with the host --------------------------------
-int scan_wg_step_rows(int layout, int M) {
-  if (layout == LAYOUT_BYTES) return SCAN_THREADS * (M < 16 ? 16 / M : 1);
-  return SCAN_THREADS;
-}
-
-// rows one wave can push into a candidate region between two prune checks
 static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
 
-void scan_geometry(int layout, int M, int W, int k, int ea, int *kp, int *ccap, int *qcap) {
+// rows the code buffer and every slice are padded to: one step of the largest workgroup
+int scan_wg_step_rows(int layout, int M) { return SCAN_MAX_THREADS * rows_per_item(layout, M); }
+
+void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap) {
   int p2 = 1;
   while (p2 < k) p2 <<= 1;
   *kp = p2;
-  const int rpi = rows_per_item(layout, M);
-  *ccap = ea ? 128 : 128 * rpi;
-  *qcap = ea ? 64 + 64 * rpi : 0;
-  (void)W;
+  *ccap = 128;  // a wave appends at most 64 rows per lock hold
+  *qcap = ea ? 64 + 64 * rows_per_item(layout, M) : 0;
 }
 
-size_t scan_lds_bytes(int layout, int M, int W, int lut_floats, int qb, int k, int ea) {
+size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves) {
   int kp, ccap, qcap;
-  scan_geometry(layout, M, W, k, ea, &kp, &ccap, &qcap);
+  scan_geometry(layout, M, k, ea, &kp, &ccap, &qcap);
   size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
   lut = (lut + 15) & ~(size_t)15;
-  const size_t per_wave = (size_t)qb * (kp + ccap) * 8 + (size_t)qcap * 4 * (1 + qb);
-  return lut + 16 + (size_t)SCAN_WAVES * per_wave;
+  const size_t sb = ((size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8 + 15) & ~(size_t)15;
+  return lut + (size_t)qb * sb + (size_t)nwaves * qcap * 4 * (1 + qb);
 }
 
 template <typename K>
@@ -895,7 +921,7 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(SCAN_THREADS), lds, st, p);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.nwaves * 64), lds, st, p);
   return hipGetLastError();
 }
 
@@ -922,7 +948,7 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
-  const size_t lds = scan_lds_bytes(p.layout, p.M, p.W, p.lut_floats, p.qb, p.k, p.ea);
+  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.k, p.ea, p.nwaves);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes_kernel, 8)

@@ -79,7 +79,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 1, opt_nwaves = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 5, created on first use
@@ -103,7 +103,7 @@ struct DeviceGuard {
 };
 
 struct Plan {
-  int qb, ea, kp, ccap, qcap, n_slices;
+  int qb, ea, kp, ccap, qcap, nwaves, n_slices;
   int64_t slice_rows;
   size_t lds;
 };
@@ -112,20 +112,32 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   const int ea = ix->opt_ea ? 1 : 0;
   int qb = ix->opt_qb > 0 ? ix->opt_qb : 2;
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
-  // fit LDS by shrinking the query batch
+  // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
+  // the selection state are per workgroup, the survivor queues per wave; a CU
+  // holds 160 KB of LDS and 32 waves (the scan kernels stay within 64 VGPRs
+  // for Qb <= 2; Qb = 4 needs about twice that, i.e. half the waves).
+  const int wave_cap = qb <= 2 ? 32 : 24;
+  int best_nw = 0, best_waves = 0;
   for (;;) {
-    size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->W, ix->lut_floats, qb, k, ea);
-    if (lds <= LDS_LIMIT) break;
+    for (int nw : {4, 8, 16}) {
+      if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
+      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, nw);
+      if (lds > LDS_LIMIT) continue;
+      const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
+      if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
+    }
+    if (best_nw) break;
     if (qb > 1) qb >>= 1;
     else
       return fail(VAQHIP_EUNSUPPORTED,
-                  "lookup tables of %d floats plus top-%d buffers need %zu B of LDS (> %zu)",
-                  ix->lut_floats, k, lds, LDS_LIMIT);
+                  "lookup tables of %d floats plus top-%d buffers do not fit %zu B of LDS",
+                  ix->lut_floats, k, LDS_LIMIT);
   }
   pl->qb = qb;
   pl->ea = ea;
-  vaq::scan_geometry(ix->layout, ix->M, ix->W, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
-  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->W, ix->lut_floats, qb, k, ea);
+  pl->nwaves = best_nw;
+  vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, best_nw);
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const int64_t N = ix->N;
   const int nqb = (nq + qb - 1) / qb;
@@ -181,7 +193,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   const bool do_project = !projected && ix->has_eig;
   if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
   HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
-  const int nslots = pl.n_slices * vaq::SCAN_WAVES;
+  const int nslots = pl.n_slices;
   HIP_TRY(ix->w_part_d.ensure((size_t)chunk * nslots * k * sizeof(float)));
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
   HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
@@ -218,6 +230,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.ccap = pl.ccap;
     sp.qcap = pl.qcap;
     sp.ea = pl.ea;
+    sp.nwaves = pl.nwaves;
     sp.g_thr = ix->w_thr.as<unsigned>();
     sp.qb = pl.qb;
     sp.n_slices = pl.n_slices;
@@ -569,6 +582,10 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     ix->opt_timing = value != 0;
   } else if (k == "early_abandon") {
     ix->opt_ea = value != 0;
+  } else if (k == "waves_per_workgroup") {
+    if (value != 0 && value != 4 && value != 8 && value != 16)
+      return fail(VAQHIP_EINVAL, "waves_per_workgroup must be 0, 4, 8 or 16");
+    ix->opt_nwaves = (int)value;
   } else {
     return fail(VAQHIP_EINVAL, "unknown option '%s'", key);
   }
