@@ -79,7 +79,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import vaq_amd
-    from vaq_amd import build, harness
+    from vaq_amd import build, harness, sharding
     from vaq_amd.index import merge_topk_device
     build.build_lib()
 
@@ -99,7 +99,7 @@ def main():
     # ---------------------------------------------------------------- setup --
     t_setup = time.time()
     shard = (N + world - 1) // world
-    lo, hi = min(N, rank * shard), min(N, (rank + 1) * shard)
+    lo, hi = sharding.shard_bounds(N, world, rank)
     n_local = hi - lo
     GEN = 1 << 20  # rows per generated chunk; chunk c is the same on every rank layout
 
@@ -167,11 +167,7 @@ def main():
     def run_step():
         l, d = v.search_device(queries, k)
         if world > 1:
-            gl = torch.empty((world, nq, k), dtype=torch.int32, device=dev)
-            gd = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(gl, l)
-            dist.all_gather_into_tensor(gd, d)
-            l, d = merge_topk_device(gd, gl, k)
+            l, d = sharding.gather_and_merge(l, d, k, merge_topk_device)
         return l, d
 
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")

@@ -1,0 +1,73 @@
+// demo_vaqhip.cpp -- the query half of the reference's examples/demo_vaq.cpp
+// (:58-92 load, :336-363 search + recall) on the MI355X path.  Training is out
+// of scope (it needs glpk / armadillo in the reference), so the index is read
+// from the files `demo_vaq --save <centroids> --save-enc <codebook>` writes,
+// plus the rotation (which the reference never persists) as a raw D x D
+// float32 file.
+//
+//   demo_vaqhip --centroids c.bin --codebook cb.bin [--eigen e.f32] \
+//               --queries q.fvecs --timeseries-size 128 [--queries-size N] \
+//               --method VAQ64m8min8max8var1,HEAP --k 100 \
+//               [--groundtruth gt.ivecs] [--result out.csv] [--bits 8,8,...]
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+
+#include "vaqhip_io.hpp"
+
+using namespace vaqhip;
+
+int main(int argc, char **argv) {
+  std::map<std::string, std::string> a = {{"k", "100"}, {"method", "VAQ64m8min8max8var1,HEAP"},
+                                          {"timeseries-size", "128"}, {"queries-size", "-1"}};
+  for (int i = 1; i + 1 < argc; i += 2) {
+    if (std::strncmp(argv[i], "--", 2) != 0) { std::cerr << "bad argument " << argv[i] << "\n"; return 2; }
+    a[argv[i] + 2] = argv[i + 1];
+  }
+  for (const char *req : {"centroids", "codebook", "queries"})
+    if (!a.count(req)) { std::cerr << "missing --" << req << "\n"; return 2; }
+  try {
+    VaqHip vaq;
+    vaq.parseMethodString(a["method"]);
+    vaq.mCentroidsPerSubs = loadCentroids(a["centroids"]);
+    vaq.mCodebook = loadCodebook(a["codebook"]);
+    const int M = (int)vaq.mCentroidsPerSubs.size();
+    if (a.count("bits")) {  // --hc-bitalloc style list (demo_vaq.cpp:94-97)
+      std::stringstream ss(a["bits"]);
+      std::string t;
+      while (std::getline(ss, t, ',')) vaq.mBitsAlloc.push_back(std::atoi(t.c_str()));
+    } else {
+      for (int s = 0; s < M; s++) vaq.mBitsAlloc.push_back((int)std::lround(std::log2((double)vaq.mCentroidsPerSubs[s].rows())));
+    }
+    const int D = vaq.mTotalDim();
+    const int N = std::atoi(a["timeseries-size"].c_str());
+    if (a.count("eigen")) {
+      vaq.mEigenVectors = RowMatrixF(D, D);
+      detail::File f(a["eigen"], "rb");
+      f.read(vaq.mEigenVectors.data(), sizeof(float), (size_t)D * D);
+    }
+    RowMatrixF queries = readFVecs(a["queries"], N, std::atoi(a["queries-size"].c_str()), D - N);
+    const int k = std::atoi(a["k"].c_str());
+    std::cout << "index: " << vaq.mCodebook.rows() << " rows x " << M << " subspaces, D=" << D
+              << ", queries " << queries.rows() << ", k=" << k << std::endl;
+    vaq.sync();
+    auto t0 = std::chrono::steady_clock::now();
+    LabelDistVecF answers = vaq.search(queries, k, true);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "== Querying time: " << sec << " s (" << queries.rows() / sec << " queries/s, host buffers in and out)"
+              << std::endl;
+    if (a.count("result")) writeKNNResults(a["result"], answers, queries.rows());
+    if (a.count("groundtruth")) {
+      RowMatrix<int> gt = readIVecs(a["groundtruth"], k);
+      std::cout << "recall@" << k << ": " << getAvgRecall(answers.labels, gt, k)
+                << "  recall@R: " << getRecallAtR(answers.labels, gt, k) << std::endl;
+    }
+  } catch (const std::exception &e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,202 @@
+// vaqhip.hpp -- header-only C++ adapter over the C ABI (vaqhip.h) with the
+// reference's own names, so driver code written against `class VAQ`
+// (bitvecengine/VAQ.hpp:36-113) swaps the type and keeps its calls:
+//
+//     VaqHip vaq;                                   // was: VAQ vaq;
+//     vaq.parseMethodString(args["method"]);        // demo_vaq.cpp:59
+//     vaq.mCentroidsPerSubs = ...; vaq.mBitsAlloc = ...; vaq.mCodebook = ...;
+//     LabelDistVecF answers = vaq.search(queries, k, true);   // demo_vaq.cpp:339
+//
+// No Eigen dependency: matrices are passed as any type with data()/rows()/
+// cols() in row-major float (Eigen's RowMatrixXf qualifies), or as the plain
+// RowMatrixF below.  VaqHip::fromReference() copies the state out of a
+// reference VAQ object by duck typing (compiled only where that class exists).
+#ifndef VAQHIP_HPP_
+#define VAQHIP_HPP_
+
+#include <cstdint>
+#include <cstdio>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vaqhip.h"
+
+namespace vaqhip {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc) {
+  if (rc < 0) throw Error(rc, std::string("vaqhip: ") + vaqhip_last_error());
+}
+
+// utils/Types.hpp:98-104
+template <typename T = float> struct LabelDistVec {
+  std::vector<int> labels;
+  std::vector<T> distances;
+};
+using LabelDistVecF = LabelDistVec<>;
+
+// minimal row-major matrix (stands in for RowMatrixXf / CodebookType)
+template <typename T> struct RowMatrix {
+  std::vector<T> v;
+  size_t r = 0, c = 0;
+  RowMatrix() = default;
+  RowMatrix(size_t rows_, size_t cols_) : v(rows_ * cols_), r(rows_), c(cols_) {}
+  T *data() { return v.data(); }
+  const T *data() const { return v.data(); }
+  size_t rows() const { return r; }
+  size_t cols() const { return c; }
+  T &operator()(size_t i, size_t j) { return v[i * c + j]; }
+  const T &operator()(size_t i, size_t j) const { return v[i * c + j]; }
+};
+using RowMatrixF = RowMatrix<float>;
+using CodebookType = RowMatrix<uint16_t>;  // utils/Types.hpp:31
+
+class VaqHip {
+public:
+  struct NNMethod {  // VAQ.hpp:38-49
+    enum { Sort = 0x01u, EA = 0x02u, TI = 0x04u, Fast = 0x08u, Fast2 = 0x10u, Fast3 = 0x20u,
+           Fast4 = 0x40u, Heap = 0x80u };
+  };
+
+  // VAQ.hpp:51-75 (the members search() reads)
+  int mBitBudget = 0, mSubspaceNum = 0;
+  float mPercentVarExplained = 1.0f;
+  int mMinBitsPerSubs = 0, mMaxBitsPerSubs = 0;
+  uint32_t mMethods = NNMethod::Heap;
+  RowMatrixF mEigenVectors;                  // real part of the reference's complex matrix; empty = identity
+  std::vector<RowMatrixF> mCentroidsPerSubs;  // K_s x L each
+  std::vector<int> mBitsAlloc;
+  CodebookType mCodebook;                     // N x M uint16
+  int64_t mIdBase = 0;                        // shard offset (not in the reference: single node)
+  int mDevice = 0;
+
+  VaqHip() = default;
+  VaqHip(const VaqHip &) = delete;
+  VaqHip &operator=(const VaqHip &) = delete;
+  ~VaqHip() { vaqhip_index_destroy(h_); }
+
+  int mHighestSubs() const { return (int)mBitsAlloc.size(); }
+  int mSubsLen() const { return mCentroidsPerSubs.empty() ? 0 : (int)mCentroidsPerSubs[0].cols(); }
+  int mTotalDim() const { return mHighestSubs() * mSubsLen(); }
+  uint32_t searchMethod() const { return mMethods; }  // VAQ.hpp:106-108
+
+  // VAQ::parseMethodString, VAQ.cpp:1189-1267.  HEAP and EA are this path;
+  // other search tokens throw (the reference would run a different algorithm).
+  void parseMethodString(const std::string &methodString) {
+    std::stringstream ss(methodString);
+    std::string token;
+    while (std::getline(ss, token, ',')) {
+      if (token.rfind("VAQ", 0) == 0) {
+        int tb, sv, mn, mx;
+        float var;
+        if (std::sscanf(token.c_str(), "VAQ%dm%dmin%dmax%dvar%f", &tb, &sv, &mn, &mx, &var) == 5) {
+          mBitBudget = tb; mSubspaceNum = sv; mMinBitsPerSubs = mn; mMaxBitsPerSubs = mx;
+          mPercentVarExplained = var;
+        }
+      } else if (token.find("SORT") != std::string::npos || token.find("HEAP") != std::string::npos ||
+                 token.find("EA") != std::string::npos || token.find("TI") != std::string::npos ||
+                 token.find("FAST") != std::string::npos) {
+        uint32_t m = 0;
+        std::stringstream sm(token);
+        std::string t;
+        while (std::getline(sm, t, '_')) {
+          if (t.find("SORT") != std::string::npos) m |= NNMethod::Sort;
+          else if (t.find("HEAP") != std::string::npos) m |= NNMethod::Heap;
+          else if (t.find("EA") != std::string::npos) m |= NNMethod::EA;
+          else if (t.find("TI") != std::string::npos) m |= NNMethod::TI;
+          else if (t.find("FAST3") != std::string::npos) m |= NNMethod::Fast3;
+          else if (t.find("FAST2") != std::string::npos) m |= NNMethod::Fast2;
+          else if (t.find("FAST") != std::string::npos) m |= NNMethod::Fast;
+        }
+        if (m & ~(uint32_t)(NNMethod::Heap | NNMethod::EA))
+          throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: method '" + token + "' is outside the HEAP/EA path");
+        mMethods = m;
+      }
+    }
+  }
+
+  // Push the public members to the GPU (called lazily by search()).
+  void sync() {
+    const int M = mHighestSubs();
+    if (M == 0 || (int)mCentroidsPerSubs.size() != M) throw Error(VAQHIP_EINVAL, "vaqhip: state not set");
+    if (!h_) {
+      std::vector<const float *> cp(M);
+      for (int s = 0; s < M; s++) {
+        if ((int)mCentroidsPerSubs[s].rows() != (1 << mBitsAlloc[s]))
+          throw Error(VAQHIP_EINVAL, "vaqhip: centroid rows != 1 << bits");
+        cp[s] = mCentroidsPerSubs[s].data();
+      }
+      check(vaqhip_index_create(&h_, mTotalDim(), M, mBitsAlloc.data(), cp.data(),
+                                mEigenVectors.rows() ? mEigenVectors.data() : nullptr, mDevice));
+      codes_set_ = false;
+    }
+    if (!codes_set_) {
+      if (mCodebook.cols() != (size_t)M && mCodebook.rows() != 0)
+        throw Error(VAQHIP_EINVAL, "vaqhip: mCodebook is not N x M");
+      check(vaqhip_index_set_codes_u16(h_, mCodebook.data(), (int64_t)mCodebook.rows(), mIdBase));
+      codes_set_ = true;
+    }
+  }
+  // call after changing any public member
+  void invalidate() {
+    vaqhip_index_destroy(h_);
+    h_ = nullptr;
+    codes_set_ = false;
+  }
+
+  // VAQ::search, VAQ.hpp:102 / VAQ.cpp:776-847
+  template <class Mat> LabelDistVecF search(const Mat &XTest, const int k, bool verbose = false) {
+    (void)verbose;
+    if (!(mMethods & (NNMethod::Heap | NNMethod::EA)))
+      throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: only HEAP / EA are implemented on this path");
+    sync();
+    LabelDistVecF ret;
+    const size_t nq = (size_t)XTest.rows();
+    ret.labels.resize(k * nq);
+    ret.distances.resize(k * nq);
+    if ((int)XTest.cols() != mTotalDim()) throw Error(VAQHIP_EINVAL, "vaqhip: XTest has the wrong width");
+    check(vaqhip_search(h_, XTest.data(), (int)nq, k, ret.labels.data(), ret.distances.data()));
+    return ret;
+  }
+
+  // Copy the search state out of a reference `VAQ` object (duck-typed: the
+  // members of VAQ.hpp:51-75, Eigen matrices).  Instantiate only in a
+  // translation unit that includes the reference's VAQ.hpp.
+  template <class RefVAQ> void fromReference(const RefVAQ &v) {
+    invalidate();
+    mBitBudget = v.mBitBudget; mSubspaceNum = v.mSubspaceNum;
+    mMinBitsPerSubs = v.mMinBitsPerSubs; mMaxBitsPerSubs = v.mMaxBitsPerSubs;
+    mMethods = v.mMethods;
+    mBitsAlloc.assign(v.mBitsAlloc.begin(), v.mBitsAlloc.begin() + v.mHighestSubs);
+    mCentroidsPerSubs.clear();
+    for (int s = 0; s < v.mHighestSubs; s++) {
+      const auto &c = v.mCentroidsPerSubs[s];  // RowMatrix<float>
+      RowMatrixF m(c.rows(), c.cols());
+      for (size_t i = 0; i < m.rows(); i++)
+        for (size_t j = 0; j < m.cols(); j++) m(i, j) = c(i, j);
+      mCentroidsPerSubs.push_back(m);
+    }
+    const size_t D = v.mEigenVectors.rows();
+    mEigenVectors = RowMatrixF(D, v.mEigenVectors.cols());
+    for (size_t i = 0; i < D; i++)
+      for (size_t j = 0; j < mEigenVectors.cols(); j++) mEigenVectors(i, j) = v.mEigenVectors(i, j).real();
+    mCodebook = CodebookType(v.mCodebook.rows(), v.mCodebook.cols());
+    for (size_t i = 0; i < mCodebook.rows(); i++)
+      for (size_t j = 0; j < mCodebook.cols(); j++) mCodebook(i, j) = v.mCodebook(i, j);
+  }
+
+  vaqhip_index *handle() { return h_; }
+
+private:
+  vaqhip_index *h_ = nullptr;
+  bool codes_set_ = false;
+};
+
+} // namespace vaqhip
+#endif

@@ -40,5 +40,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_demo(force: bool = False) -> str:
+    """examples/demo_vaqhip.cpp: plain g++ against the C ABI (no hipcc needed)."""
+    lib = build_lib()
+    out_dir = os.path.join(ROOT, "examples", "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "demo_vaqhip")
+    src = os.path.join(ROOT, "examples", "demo_vaqhip.cpp")
+    hdrs = [os.path.join(ROOT, "include", h) for h in ("vaqhip.h", "vaqhip.hpp", "vaqhip_io.hpp")]
+    if not force and os.path.exists(exe) and all(
+            os.path.getmtime(f) <= os.path.getmtime(exe) for f in [src, lib] + hdrs):
+        return exe
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+           src, "-o", exe, "-L" + LIBDIR, "-lvaqhip", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
