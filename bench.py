@@ -47,8 +47,9 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--qb", type=int, default=0, help="queries per pass (0 = library default)")
     ap.add_argument("--slices", type=int, default=0)
-    ap.add_argument("--ea", type=int, default=1, help="early abandon (two-phase scan) on/off")
+    ap.add_argument("--ea", type=int, default=3, help="early abandon: 0 off, 1 queue, 2 in place, 3 auto")
     ap.add_argument("--nwaves", type=int, default=0, help="wavefronts per scan workgroup (0 = auto)")
+    ap.add_argument("--seed", type=int, default=1, help="threshold-seeding pre-pass on/off")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -162,6 +163,7 @@ def main():
     v.set_option("early_abandon", args.ea)
     if args.nwaves:
         v.set_option("waves_per_workgroup", args.nwaves)
+    v.set_option("seed_thresholds", args.seed)
     info = v.info()
 
     def run_step():
@@ -214,7 +216,7 @@ def main():
         "effective_per_query_GBps": round(float(n_local) * info["algo_code_bytes"] * nq /
                                           (tm["scan_ms"] * 1e-3) / 1e9, 1) if tm["scan_ms"] > 0 else 0.0,
         "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
-                             "merge": round(tm["merge_ms"], 4)},
+                             "threshold_seed": round(tm["seed_ms"], 4), "merge": round(tm["merge_ms"], 4)},
         "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
     }
 

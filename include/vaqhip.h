@@ -145,22 +145,30 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *   "timing"            1: record hipEvents (on the search's own stream) around
  *                       each kernel of every following search, up to 256
  *                       searches between two vaqhip_last_timing reads
- *   "early_abandon"     1 (default): two-phase scan that drops a row once a partial
- *                       sum exceeds the query's current k-th best (the GPU form
- *                       of VAQ::searchEarlyAbandon, VAQ.cpp:1694-1727); 0: every
- *                       row is summed completely (VAQ::searchHeap).  Results are
- *                       identical either way.                                 */
+ *   "waves_per_workgroup" 0 = auto (most wavefronts per CU), else 4, 8 or 16
+ *   "seed_thresholds"   1 (default): when a query's rows are split over several
+ *                       workgroups, a pre-pass over 1/64 of the rows seeds their
+ *                       admission thresholds; 0: every workgroup warms up alone
+ *   "early_abandon"     how a row is dropped once a partial sum exceeds the query's
+ *                       current k-th best (the GPU forms of VAQ::searchEarlyAbandon,
+ *                       VAQ.cpp:1694-1727); results are identical for every value:
+ *                       0 never (VAQ::searchHeap as written), 1 survivors are
+ *                       compacted through an LDS queue, 2 survivors finish in
+ *                       place, 3 (default) 1 or 2 chosen per search            */
 int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
 
 typedef struct {
-  float project_ms, lut_ms, scan_ms, merge_ms; /* mean device time per search over the
-                                                  searches recorded since the last read  */
+  float project_ms, lut_ms, seed_ms, scan_ms, merge_ms; /* mean device time per search over
+                                                  the searches recorded since the last read;
+                                                  seed = threshold pre-pass, scan = the
+                                                  full code scan kernel alone             */
   int n_searches;                              /* how many searches that mean covers   */
   int queries_per_pass;                        /* Qb actually used              */
   int slices;                                  /* row slices per query batch    */
   int workgroups;                              /* scan kernel grid size         */
   int passes;                                  /* ceil(nq / Qb)                 */
   int lds_bytes;                               /* LDS per scan workgroup        */
+  int seed_slices;                             /* row slices of the pre-pass (0 = none) */
 } vaqhip_timing;
 int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
 

@@ -56,7 +56,7 @@ def test_golden(vaqlib, oracle, name):
         if not key.startswith("labels_k"):
             continue
         k = int(key[len("labels_k"):])
-        for qb, ea in [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0)]:
+        for qb, ea in [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0), (1, 2), (2, 2), (4, 2), (2, 3)]:
             v.set_option("queries_per_pass", qb)
             v.set_option("early_abandon", ea)
             ans = v.search(z["X"], k)
@@ -94,7 +94,7 @@ def test_search_matches_oracle(vaqlib, oracle, cfg):
     assert np.array_equal(lut.view(np.uint32), o_lut.view(np.uint32))
     ties = 0
     for qb, slices, ea in [(1, 0, 1), (2, 0, 1), (4, 0, 1), (2, 1, 1), (2, 3, 1), (1, 7, 1),
-                           (2, 0, 0), (4, 3, 0), (1, 1, 0)]:
+                           (2, 0, 0), (4, 3, 0), (1, 1, 0), (2, 0, 2), (1, 5, 2), (4, 1, 2)]:
         v.set_option("queries_per_pass", qb)
         v.set_option("slices", slices)
         v.set_option("early_abandon", ea)
@@ -182,14 +182,14 @@ def test_full_size_properties(vaqlib):
     v = make_index(c)
     k = 100
     res = {}
-    for qb, ea, sl in [(1, 0, 0), (1, 1, 0), (2, 1, 0), (4, 1, 0), (2, 0, 5), (2, 1, 16), (4, 1, 61)]:
+    for qb, ea, sl in [(1, 0, 0), (1, 1, 0), (2, 1, 0), (4, 1, 0), (2, 0, 5), (2, 1, 16), (4, 1, 61), (2, 2, 0), (1, 2, 33)]:
         v.set_option("queries_per_pass", qb)
         v.set_option("early_abandon", ea)
         v.set_option("slices", sl)
         a = v.search(c["X"], k)
         res[(qb, ea, sl)] = (a.labels.reshape(64, k).copy(), a.distances.reshape(64, k).copy())
     v.set_option("slices", 0)
-    v.set_option("early_abandon", 1)
+    v.set_option("early_abandon", 3)
     base = res[(1, 0, 0)]
     for key, r in res.items():
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), key
@@ -241,3 +241,30 @@ def test_cpp_demo_driver(vaqlib, oracle, tmp_path):
     d_got = np.take_along_axis(ad, got, axis=1).astype(np.float32)
     assert_topk_matches(got.astype(np.int32), d_got, o_lab, o_dis, ad, what="cpp demo")
     assert "recall@100: 1" in r.stdout
+
+
+@pytest.mark.parametrize("bits", [[8] * 16, [12, 10, 9, 8, 8, 7, 6, 4]], ids=["m16", "nonuniform"])
+def test_seeded_multislice(vaqlib, oracle, bits):
+    """Few queries over many rows: rows are split over hundreds of workgroups,
+    the sampling pre-pass seeds their thresholds and they exchange them through
+    global memory.  Must equal the oracle and the unseeded / single-slice runs."""
+    c = make_case(701, 128, bits, 2_400_000, 3, dup_frac=0.01)
+    v = make_index(c)
+    k = 100
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=3)
+    ad = oracle_all_dists(oracle, c, Xp)
+    seen = []
+    for seed, slices, qb, ea in [(1, 300, 2, 1), (0, 300, 2, 1), (1, 0, 1, 3), (1, 1, 2, 3), (1, 257, 4, 2), (1, 300, 2, 2)]:
+        v.set_option("seed_thresholds", seed)
+        v.set_option("early_abandon", ea)
+        v.set_option("slices", slices)
+        v.set_option("queries_per_pass", qb)
+        v.set_option("timing", 1)
+        a = v.search(c["X"], k)
+        t = v.last_timing()
+        seen.append((seed, slices, t["slices"], t["seed_slices"]))
+        assert_topk_matches(a.labels.reshape(3, k), a.distances.reshape(3, k), o_lab, o_dis, ad,
+                            what=f"seed={seed} slices={slices} qb={qb}")
+    assert seen[0][2] > 1 and seen[0][3] > 0, seen     # auto plan: multi-slice and seeded
+    assert seen[1][3] == 0 and seen[3][3] == 0, seen   # seeding off / single slice

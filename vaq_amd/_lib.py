@@ -40,9 +40,11 @@ class Info(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("project_ms", C.c_float), ("lut_ms", C.c_float), ("scan_ms", C.c_float),
+    _fields_ = [("project_ms", C.c_float), ("lut_ms", C.c_float), ("seed_ms", C.c_float),
+                ("scan_ms", C.c_float),
                 ("merge_ms", C.c_float), ("n_searches", C.c_int), ("queries_per_pass", C.c_int), ("slices", C.c_int),
-                ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int)]
+                ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int),
+                ("seed_slices", C.c_int)]
 
 
 _lib = None

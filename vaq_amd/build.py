@@ -34,6 +34,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
            "-ffp-contract=off", "-fno-fast-math", "-Wall",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += os.environ.get("VAQ_EXTRA_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -21,6 +21,14 @@ struct SubDesc {
 };
 
 enum Layout { LAYOUT_BYTES = 0, LAYOUT_BITS = 1 };
+// early-abandon forms of the scan (identical results):
+//   EA_NONE    every row summed completely (VAQ::searchHeap as written)
+//   EA_QUEUE   survivors of the first group compacted into an LDS queue and
+//              finished 64 at a time (best when many query batches share the
+//              code stream through cache: instruction-bound)
+//   EA_INPLACE survivors finish in place under the EXEC mask (no queue, no
+//              re-read of their codes: best for a single HBM-bound pass)
+enum EarlyAbandon { EA_NONE = 0, EA_QUEUE = 1, EA_INPLACE = 2 };
 
 // rows per planar tile of the bit-packed layout (one wavefront step)
 constexpr int TILE_ROWS = 64;
@@ -45,11 +53,14 @@ struct ScanParams {
   int ccap;               // slots of its candidate region
   int qcap;               // slots of a wave's survivor queue (early abandon)
   int nwaves;             // wavefronts per workgroup
-  int ea;                 // 1: two-phase early abandon (results identical to 0)
+  int ea;                 // EarlyAbandon
   unsigned *g_thr;        // [nq] shared threshold distances (float bits), preset to FLT_MAX
   int qb;                 // queries per pass (1, 2, 4)
   int n_slices;           // row slices per query batch
   int64_t slice_rows;     // rows per slice (multiple of the workgroup step)
+  int64_t slice_stride;   // rows between slice starts (== slice_rows for a full scan,
+                          // larger for the sampling pre-pass)
+  int share_thr;          // 1: exchange thresholds between workgroups through g_thr
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
@@ -78,10 +89,15 @@ int scan_wg_step_rows(int layout, int M);
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
 // in_final != 0: inputs use the API's -1 / FLT_MAX convention for empty slots
 // candidate i of list l of query q sits at l*list_stride + q*query_stride + i
+// labels == nullptr: no result is written (only thr_out is wanted).
+// thr_out (optional): [nq] float bits, lowered to each query's k-th distance.
+// More than 64 lists are folded in levels through scratch_d/scratch_id
+// (merge_scratch_elems() elements each).
+size_t merge_scratch_elems(int n_lists, int nq, int k);
 hipError_t launch_merge(const float *part_d, const int *part_id, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,
-                        hipStream_t st);
+                        unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st);
 
 } // namespace vaq
 #endif

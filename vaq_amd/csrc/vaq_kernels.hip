@@ -386,7 +386,10 @@ __device__ __forceinline__ bool sel_fold(const SelView &v, int k, int kp, int la
 __device__ __forceinline__ int xcd_virtual_id(int b, int G) { return (b & 7) * (G >> 3) + (b >> 3); }
 
 constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
-constexpr int PREFETCH = 2;        // items loaded ahead of the one being processed
+#ifndef VAQ_PREFETCH
+#define VAQ_PREFETCH 2
+#endif
+constexpr int PREFETCH = VAQ_PREFETCH;  // items loaded ahead of the one being processed
 constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
 constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
 constexpr int THR_GLOBAL_EVERY = 64;
@@ -418,7 +421,7 @@ template <int QB> struct ScanCtx {
     ccap = p.ccap;
     qcap = p.qcap;
     qcnt = 0;
-    multi_slice = p.n_slices > 1;
+    multi_slice = p.share_thr != 0;
     g_thr = p.g_thr;
     lut = reinterpret_cast<LT *>(smem);
     size_t off = ((size_t)lut_entries * sizeof(LT) + 15) & ~(size_t)15;
@@ -615,7 +618,7 @@ template <int M> struct BytesItem {
 //       reference's order, abandoning after each, and admit to the k-min.
 // Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
-template <int M, int QB, bool EA>
+template <int M, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams
   // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the largest
   // workgroup step and the code buffer is padded to a multiple of it, so every
   // load is in bounds; rows >= n_rows are masked out.
-  const int r0 = (int)((int64_t)slice * p.slice_rows);
+  const int r0 = (int)((int64_t)slice * p.slice_stride);
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
   const int step_items = nthreads;  // items per workgroup step
@@ -687,7 +690,11 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams
     uint32_t cw[WPR];
     cw[0] = 0u;
 #pragma unroll
+#ifdef VAQ_EXPERIMENT_NO_REREAD   // timing experiment only: results are wrong
+    for (int i = 1; i < WPR; i++) cw[i] = (unsigned)rid * 2654435761u;
+#else
     for (int i = 1; i < WPR; i++) cw[i] = codes[(int64_t)rid * WPR + i];
+#endif
     finish(cw, acc, rid, ok);
   };
 
@@ -731,12 +738,21 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams
           group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
           live = cx.survives(part[r]);
         }
-        cx.push(live, row0 + r, part[r]);
+        if (EA == EA_QUEUE) {
+          cx.push(live, row0 + r, part[r]);
+        } else {
+          // EA_INPLACE: the live lanes finish their rows where they stand
+          uint32_t cw[WPR];
+#pragma unroll
+          for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
+          finish(cw, part[r], row0 + r, live);
+        }
       }
-      while (cx.qcnt >= 64) drain(64);
+      if (EA == EA_QUEUE)
+        while (cx.qcnt >= 64) drain(64);
     }
   }
-  if (EA && cx.qcnt > 0) drain(cx.qcnt);
+  if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);
   cx.write_out(p, slice, qbatch);
 }
 
@@ -757,7 +773,7 @@ template <int W> struct BitsItem {
   }
 };
 
-template <int W, int QB, bool EA>
+template <int W, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
@@ -776,7 +792,7 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
   __syncthreads();
 
-  const int r0 = (int)((int64_t)slice * p.slice_rows);
+  const int r0 = (int)((int64_t)slice * p.slice_stride);
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
   const int64_t tile0 = r0 / TILE_ROWS + wave;
@@ -869,8 +885,32 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
         chain(3, lut[s3.lut_off + c3], acc, dism);
         live = cx.survives(acc);
       }
-      cx.push(live, row, acc);
-      while (cx.qcnt >= 64) drain(64);
+      if (EA == EA_QUEUE) {
+        cx.push(live, row, acc);
+        while (cx.qcnt >= 64) drain(64);
+      } else {
+        // EA_INPLACE: the live lanes finish their rows from the words they hold
+        bool alive = live;
+        int s = 4;
+#pragma unroll
+        for (int wi = 0; wi < W; wi++) {
+          const uint32_t lo = cur.w[wi];
+          const uint32_t hi = (wi + 1 < W) ? cur.w[wi + 1 < W ? wi + 1 : wi] : 0u;
+          const int s_end = first_sub[wi + 1];
+          if (s < first_sub[wi]) s = first_sub[wi];
+          for (; s < s_end; s++) {
+            if (s < 4) continue;
+            const SubDesc sd = sub[s];
+            if (alive) {
+              const uint32_t c =
+                  __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
+              chain(s, lut[sd.lut_off + c], acc, dism);
+              if ((s & 3) == 3) alive = cx.survives(acc);
+            }
+          }
+        }
+        cx.admit(acc, row, alive);
+      }
     } else {
       int s = 0;
 #pragma unroll
@@ -888,7 +928,7 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
       cx.admit(acc, row, valid);
     }
   }
-  if (EA && cx.qcnt > 0) drain(cx.qcnt);
+  if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);
   cx.write_out(p, slice, qbatch);
 }
 
@@ -903,7 +943,7 @@ void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qc
   while (p2 < k) p2 <<= 1;
   *kp = p2;
   *ccap = 128;  // a wave appends at most 64 rows per lock hold
-  *qcap = ea ? 64 + 64 * rows_per_item(layout, M) : 0;
+  *qcap = ea == EA_QUEUE ? 64 + 64 * rows_per_item(layout, M) : 0;
 }
 
 size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves) {
@@ -925,21 +965,19 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
   return hipGetLastError();
 }
 
+#define VAQ_DISPATCH_EA(KERNEL, A, Q)                                                     \
+  switch (p.ea) {                                                                         \
+  case EA_NONE: return launch_scan_kernel(KERNEL<A, Q, EA_NONE>, p, lds, grid, st);       \
+  case EA_QUEUE: return launch_scan_kernel(KERNEL<A, Q, EA_QUEUE>, p, lds, grid, st);     \
+  case EA_INPLACE: return launch_scan_kernel(KERNEL<A, Q, EA_INPLACE>, p, lds, grid, st); \
+  default: return hipErrorInvalidValue;                                                   \
+  }
 #define VAQ_DISPATCH_QB(KERNEL, A)                                                        \
-  if (p.ea) {                                                                             \
-    switch (p.qb) {                                                                       \
-    case 1: return launch_scan_kernel(KERNEL<A, 1, true>, p, lds, grid, st);              \
-    case 2: return launch_scan_kernel(KERNEL<A, 2, true>, p, lds, grid, st);              \
-    case 4: return launch_scan_kernel(KERNEL<A, 4, true>, p, lds, grid, st);              \
-    default: return hipErrorInvalidValue;                                                 \
-    }                                                                                     \
-  } else {                                                                                \
-    switch (p.qb) {                                                                       \
-    case 1: return launch_scan_kernel(KERNEL<A, 1, false>, p, lds, grid, st);             \
-    case 2: return launch_scan_kernel(KERNEL<A, 2, false>, p, lds, grid, st);             \
-    case 4: return launch_scan_kernel(KERNEL<A, 4, false>, p, lds, grid, st);             \
-    default: return hipErrorInvalidValue;                                                 \
-    }                                                                                     \
+  switch (p.qb) {                                                                         \
+  case 1: VAQ_DISPATCH_EA(KERNEL, A, 1)                                                   \
+  case 2: VAQ_DISPATCH_EA(KERNEL, A, 2)                                                   \
+  case 4: VAQ_DISPATCH_EA(KERNEL, A, 4)                                                   \
+  default: return hipErrorInvalidValue;                                                   \
   }
 
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
@@ -978,32 +1016,41 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
 // ---------------------------------------------------------------------------
 constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_CAP = 2048;
+constexpr int MERGE_FANIN = 16;  // lists folded by one workgroup (16 x k <= 2048 for k <= 128: one sort)
 
+// grid = (query, group); group g folds lists [g*lists_per_group, ...).
+//  final != 0 : write labels (+id_base) / distances with -1 / FLT_MAX in empty slots
+//  final == 0 : write the group's k best as an intermediate list (raw ids, sentinels kept)
+//  thr_out    : optional [nq] float bits; receives min(thr_out[q], k-th distance) when k rows exist
 __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
     const float *__restrict__ part_d, const int *__restrict__ part_id, int n_lists,
-    int64_t list_stride, int64_t query_stride, int k, int64_t id_base, int in_final,
-    int32_t *__restrict__ labels, float *__restrict__ dist) {
+    int lists_per_group, int64_t list_stride, int64_t query_stride, int k, int64_t id_base,
+    int in_final, int final, int32_t *__restrict__ out_id, float *__restrict__ out_d,
+    unsigned *__restrict__ thr_out) {
   __shared__ float sd[MERGE_CAP];
   __shared__ int si[MERGE_CAP];
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const int64_t total = (int64_t)n_lists * k;
+  const int q = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int l0 = g * lists_per_group;
+  int l1 = l0 + lists_per_group;
+  if (l1 > n_lists) l1 = n_lists;
+  const int64_t total = (int64_t)(l1 > l0 ? l1 - l0 : 0) * k;
   int kept = 0;
   int64_t pos = 0;
   while (pos < total) {
     int take = MERGE_CAP - kept;
     if ((int64_t)take > total - pos) take = (int)(total - pos);
     for (int i = tid; i < take; i += MERGE_THREADS) {
-      int64_t c = pos + i;
-      int64_t l = c / k;
-      int j = (int)(c - l * k);
-      size_t a = (size_t)(l * list_stride + (int64_t)q * query_stride + j);
+      const int64_t c = pos + i;
+      const int64_t l = c / k;
+      const int j = (int)(c - l * k);
+      const size_t a = (size_t)((l0 + l) * list_stride + (int64_t)q * query_stride + j);
       float d = part_d[a];
       int id = part_id[a];
       if (in_final && id < 0) { d = INFINITY; id = ID_SENTINEL; }
       sd[kept + i] = d;
       si[kept + i] = id;
     }
-    int n = kept + take;
+    const int n = kept + take;
     int P = 2;
     while (P < n) P <<= 1;
     for (int i = n + tid; i < P; i += MERGE_THREADS) { sd[i] = INFINITY; si[i] = ID_SENTINEL; }
@@ -1013,19 +1060,61 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
     pos += take;
   }
   __syncthreads();
+  const size_t o = ((size_t)q * gridDim.y + g) * k;
   for (int i = tid; i < k; i += MERGE_THREADS) {
-    bool ok = i < kept && si[i] != ID_SENTINEL;
-    labels[(size_t)q * k + i] = ok ? (int32_t)(si[i] + id_base) : -1;
-    dist[(size_t)q * k + i] = ok ? sd[i] : FLT_MAX;
+    const bool ok = i < kept && si[i] != ID_SENTINEL;
+    if (final) {
+      out_id[o + i] = ok ? (int32_t)(si[i] + id_base) : -1;
+      out_d[o + i] = ok ? sd[i] : FLT_MAX;
+    } else {
+      out_id[o + i] = ok ? si[i] : ID_SENTINEL;
+      out_d[o + i] = ok ? sd[i] : INFINITY;
+    }
   }
+  if (thr_out && tid == 0 && kept >= k && si[k - 1] != ID_SENTINEL)
+    atomicMin(&thr_out[q], __builtin_bit_cast(unsigned, sd[k - 1]));
+}
+
+size_t merge_scratch_elems(int n_lists, int nq, int k) {
+  size_t lists = 1;  // room for one discarded result list (labels == nullptr)
+  for (size_t n = (size_t)n_lists; n > (size_t)MERGE_FANIN;) {
+    n = (n + MERGE_FANIN - 1) / MERGE_FANIN;
+    lists += n;
+  }
+  return lists * (size_t)nq * k;
 }
 
 hipError_t launch_merge(const float *part_d, const int *part_id, int n_lists, int64_t list_stride,
                         int64_t query_stride, int nq, int k, int64_t id_base, int in_final,
-                        int32_t *labels, float *dist, hipStream_t st) {
+                        int32_t *labels, float *dist, unsigned *thr_out, float *scratch_d,
+                        int *scratch_id, hipStream_t st) {
   if (nq == 0 || k == 0) return hipSuccess;
-  hipLaunchKernelGGL(merge_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, part_d, part_id, n_lists,
-                     list_stride, query_stride, k, id_base, in_final, labels, dist);
+  const float *cur_d = part_d;
+  const int *cur_id = part_id;
+  float *sd = scratch_d;
+  int *si = scratch_id;
+  if (!labels && (!sd || !si)) return hipErrorInvalidValue;
+  // fold 64 lists at a time into intermediate lists until one workgroup can finish
+  while (n_lists > MERGE_FANIN) {
+    const int groups = (n_lists + MERGE_FANIN - 1) / MERGE_FANIN;
+    if (!sd || !si) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_kernel, dim3(nq, groups), dim3(MERGE_THREADS), 0, st, cur_d, cur_id,
+                       n_lists, MERGE_FANIN, list_stride, query_stride, k, (int64_t)0, in_final, 0, si,
+                       sd, (unsigned *)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    cur_d = sd;
+    cur_id = si;
+    sd += (size_t)nq * groups * k;
+    si += (size_t)nq * groups * k;
+    n_lists = groups;
+    list_stride = k;
+    query_stride = (int64_t)groups * k;
+    in_final = 0;
+  }
+  hipLaunchKernelGGL(merge_kernel, dim3(nq, 1), dim3(MERGE_THREADS), 0, st, cur_d, cur_id, n_lists,
+                     n_lists > 0 ? n_lists : 1, list_stride, query_stride, k, id_base, in_final,
+                     labels ? 1 : 0, labels ? labels : si, labels ? dist : sd, thr_out);
   return hipGetLastError();
 }
 

@@ -63,6 +63,10 @@ constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
+constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short to need seeding
+constexpr int64_t SEED_FRACTION = 64;          // the pre-pass scans N / 64 rows
+constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
+constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to which EA_INPLACE is chosen
 
 } // namespace
 
@@ -76,13 +80,13 @@ struct vaqhip_index {
   bool has_eig = false;
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
-  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr;
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 1, opt_nwaves = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
-  std::vector<hipEvent_t> ev;   // EV_SETS * 5, created on first use
+  std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
   int ev_used = 0;              // searches recorded since the last vaqhip_last_timing
   vaqhip_timing last = {};
   std::mutex mu;
@@ -106,10 +110,21 @@ struct Plan {
   int qb, ea, kp, ccap, qcap, nwaves, n_slices;
   int64_t slice_rows;
   size_t lds;
+  // sampling pre-pass that seeds the shared thresholds (0 slices = none)
+  int seed_slices;
+  int64_t seed_rows, seed_stride;
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
-  const int ea = ix->opt_ea ? 1 : 0;
+  // early-abandon form: 1 = queue, 2 = in place, 3 = auto (in place when few
+  // query batches stream a database that does not fit the 256 MB Infinity
+  // Cache, i.e. the scan is HBM-bound rather than instruction-bound)
+  int ea = ix->opt_ea;
+  if (ea == 3) {
+    const double stream_bytes = (double)ix->N * ((ix->total_bits + 7) / 8);
+    const int nqb_est = (nq + 1) / 2;
+    ea = (stream_bytes > 256e6 && nqb_est <= INPLACE_MAX_BATCHES) ? vaq::EA_INPLACE : vaq::EA_QUEUE;
+  }
   int qb = ix->opt_qb > 0 ? ix->opt_qb : 2;
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
@@ -155,12 +170,33 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   s = N > 0 ? (N + rows - 1) / rows : 1;
   pl->n_slices = (int)s;
   pl->slice_rows = rows;
+  // Threshold seeding: when a query's rows are split over several workgroups,
+  // each would otherwise warm its admission threshold up on its own slice
+  // (k-th best of the few rows it has seen).  A pre-pass scans ~1/64 of the
+  // rows, spread evenly, merges its top-k and publishes the k-th distance as
+  // the starting threshold of every workgroup of the full scan: an upper
+  // bound of the final k-th, so results are unchanged.
+  pl->seed_slices = 0;
+  pl->seed_rows = pl->seed_stride = 0;
+  if (ea && ix->opt_seed && s >= SEED_MIN_SLICES && N >= SEED_MIN_ROWS) {
+    const int64_t sample = std::max<int64_t>(N / SEED_FRACTION, (int64_t)16 * k);
+    // small workgroups (4 waves) and many slices: the pre-pass runs with cold
+    // thresholds, where the waves of a workgroup queue on its admission lock
+    int64_t ss = std::min<int64_t>(1024, std::max<int64_t>(8, sample / 8192));
+    int64_t srows = ((sample / ss + step - 1) / step) * step;
+    int64_t stride = (N / ss / step) * step;
+    if (stride >= srows && srows > 0) {
+      pl->seed_slices = (int)ss;
+      pl->seed_rows = srows;
+      pl->seed_stride = stride;
+    }
+  }
   return VAQHIP_OK;
 }
 
 int ensure_events(vaqhip_index *ix) {
   if (!ix->ev.empty()) return VAQHIP_OK;
-  std::vector<hipEvent_t> ev(vaqhip_index::EV_SETS * 5);
+  std::vector<hipEvent_t> ev(vaqhip_index::EV_SETS * 6);
   for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
   ix->ev.swap(ev);
   return VAQHIP_OK;
@@ -181,7 +217,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     int rc = ensure_events(ix);
     if (rc) return rc;
     if (ix->ev_used >= vaqhip_index::EV_SETS) timing = false;  // ring full: stop recording
-    else ev = ix->ev.data() + (size_t)ix->ev_used * 5;
+    else ev = ix->ev.data() + (size_t)ix->ev_used * 6;
   }
   vaqhip_timing tm = {};
   Plan pl;
@@ -193,10 +229,15 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   const bool do_project = !projected && ix->has_eig;
   if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
   HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
-  const int nslots = pl.n_slices;
+  const int nslots = std::max(pl.n_slices, pl.seed_slices);
   HIP_TRY(ix->w_part_d.ensure((size_t)chunk * nslots * k * sizeof(float)));
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
   HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
+  {
+    const size_t ms = vaq::merge_scratch_elems(nslots, chunk, k);
+    HIP_TRY(ix->w_ms_d.ensure(std::max<size_t>(ms, 1) * sizeof(float)));
+    HIP_TRY(ix->w_ms_id.ensure(std::max<size_t>(ms, 1) * sizeof(int)));
+  }
 
   if (timing && nq > chunk)
     return fail(VAQHIP_EUNSUPPORTED, "timing supports at most %d queries per call", QUERY_CHUNK);
@@ -233,20 +274,36 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.nwaves = pl.nwaves;
     sp.g_thr = ix->w_thr.as<unsigned>();
     sp.qb = pl.qb;
-    sp.n_slices = pl.n_slices;
-    sp.slice_rows = pl.slice_rows;
     sp.part_d = ix->w_part_d.as<float>();
     sp.part_id = ix->w_part_id.as<int>();
     int grid = 0;
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
-    if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+    if (ix->N > 0 && pl.seed_slices > 0) {
+      sp.n_slices = pl.seed_slices;
+      sp.slice_rows = pl.seed_rows;
+      sp.slice_stride = pl.seed_stride;
+      sp.share_thr = 1;
+      sp.nwaves = 4;
+      HIP_TRY(vaq::launch_scan(sp, nullptr, st));
+      sp.nwaves = pl.nwaves;
+      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, pl.seed_slices, k, (int64_t)pl.seed_slices * k, n,
+                                k, 0, 0, nullptr, nullptr, ix->w_thr.as<unsigned>(),
+                                ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
+    }
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));
-    const int lists = ix->N > 0 ? nslots : 0;
-    HIP_TRY(vaq::launch_merge(ix->w_part_d.as<float>(), ix->w_part_id.as<int>(), lists, k,
-                              (int64_t)nslots * k, n, k, ix->id_base, 0,
-                              d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st));
+    sp.n_slices = pl.n_slices;
+    sp.slice_rows = pl.slice_rows;
+    sp.slice_stride = pl.slice_rows;
+    sp.share_thr = pl.n_slices > 1;
+    if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
+    const int lists = ix->N > 0 ? pl.n_slices : 0;
+    HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, lists, k, (int64_t)pl.n_slices * k, n, k,
+                              ix->id_base, 0, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k,
+                              nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
+    if (timing) HIP_TRY(hipEventRecord(ev[5], st));
+    tm.seed_slices = pl.seed_slices;
     tm.queries_per_pass = pl.qb;
     tm.slices = pl.n_slices;
     tm.workgroups = grid;
@@ -372,7 +429,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_labels,
-                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr})
+                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id})
       b->release();
   }
   delete ix;
@@ -545,8 +602,10 @@ int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists, const int
     return fail(VAQHIP_EINVAL, "null pointer");
   DeviceGuard g(device_id);
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
+  if (n_lists > 16) return fail(VAQHIP_EUNSUPPORTED, "at most 16 lists per merge");
   HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, n_lists, (int64_t)nq * k, k, nq, k, 0, 1,
-                            d_labels_out, d_dist_out, static_cast<hipStream_t>(stream)));
+                            d_labels_out, d_dist_out, nullptr, nullptr, nullptr,
+                            static_cast<hipStream_t>(stream)));
   return VAQHIP_OK;
 }
 
@@ -581,7 +640,10 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "timing") {
     ix->opt_timing = value != 0;
   } else if (k == "early_abandon") {
-    ix->opt_ea = value != 0;
+    if (value < 0 || value > 3) return fail(VAQHIP_EINVAL, "early_abandon must be 0..3");
+    ix->opt_ea = (int)value;
+  } else if (k == "seed_thresholds") {
+    ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
     if (value != 0 && value != 4 && value != 8 && value != 16)
       return fail(VAQHIP_EINVAL, "waves_per_workgroup must be 0, 4, 8 or 16");
@@ -597,11 +659,11 @@ int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out) {
   std::lock_guard<std::mutex> lk(ix->mu);
   if (ix->ev_used > 0) {
     DeviceGuard g(ix->device);
-    double acc[4] = {0, 0, 0, 0};
+    double acc[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < ix->ev_used; i++) {
-      hipEvent_t *ev = ix->ev.data() + (size_t)i * 5;
-      HIP_TRY(hipEventSynchronize(ev[4]));
-      for (int j = 0; j < 4; j++) {
+      hipEvent_t *ev = ix->ev.data() + (size_t)i * 6;
+      HIP_TRY(hipEventSynchronize(ev[5]));
+      for (int j = 0; j < 5; j++) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ev[j], ev[j + 1]));
         acc[j] += ms;
@@ -610,8 +672,9 @@ int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out) {
     const double n = ix->ev_used;
     ix->last.project_ms = (float)(acc[0] / n);
     ix->last.lut_ms = (float)(acc[1] / n);
-    ix->last.scan_ms = (float)(acc[2] / n);
-    ix->last.merge_ms = (float)(acc[3] / n);
+    ix->last.seed_ms = (float)(acc[2] / n);
+    ix->last.scan_ms = (float)(acc[3] / n);
+    ix->last.merge_ms = (float)(acc[4] / n);
     ix->last.n_searches = ix->ev_used;
     ix->ev_used = 0;
   }
