@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--shard", default="auto", choices=["auto", "rows", "queries"],
+                    help="multi-GPU: shard code rows (all-gather + merge), or replicate codes and shard queries")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     return ap.parse_args()
 
 
@@ -72,12 +77,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import vaq_amd
     from vaq_amd import build, harness, sharding
@@ -99,8 +109,13 @@ def main():
 
     # ---------------------------------------------------------------- setup --
     t_setup = time.time()
-    shard = (N + world - 1) // world
-    lo, hi = sharding.shard_bounds(N, world, rank)
+    code_bytes_est = (sum(bits) + 7) // 8
+    mode = sharding.choose_mode(N, code_bytes_est, nq, world, args.shard)
+    if mode == "rows":
+        lo, hi = sharding.shard_bounds(N, world, rank)
+    else:
+        lo, hi = 0, N
+    shard = hi - lo if mode == "queries" else (N + world - 1) // world
     n_local = hi - lo
     GEN = 1 << 20  # rows per generated chunk; chunk c is the same on every rank layout
 
@@ -156,6 +171,9 @@ def main():
     torch.cuda.empty_cache()
 
     queries = harness.sift_like(nq, D, stream=7, device=dev)
+    q_lo, q_hi = (0, nq) if mode == "rows" else sharding.shard_bounds(nq, world, rank)
+    my_queries = queries[q_lo:q_hi].contiguous()
+    nq_local = q_hi - q_lo
     if args.qb:
         v.set_option("queries_per_pass", args.qb)
     if args.slices:
@@ -167,9 +185,12 @@ def main():
     info = v.info()
 
     def run_step():
-        l, d = v.search_device(queries, k)
+        l, d = v.search_device(my_queries, k)
         if world > 1:
-            l, d = sharding.gather_and_merge(l, d, k, merge_topk_device)
+            if mode == "rows":
+                l, d = sharding.gather_and_merge(l, d, k, merge_topk_device)
+            else:
+                l, d = sharding.gather_query_slices(l, d, nq)
         return l, d
 
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")
@@ -204,6 +225,7 @@ def main():
     # ------------------------------------------------------------- roofline --
     # unit = one database row scanned in one pass; bytes = ceil(sum bits / 8);
     # one launch scans n_local rows in `passes` = ceil(nq / Qb) passes.
+    # (per rank: this rank's rows x the passes its own queries need)
     algo_bytes = float(n_local) * info["algo_code_bytes"] * tm["passes"]
     achieved = algo_bytes / (tm["scan_ms"] * 1e-3) / 1e9 if tm["scan_ms"] > 0 else 0.0
     roofline = {
@@ -213,7 +235,7 @@ def main():
         "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
         "queries_per_pass": tm["queries_per_pass"], "passes": tm["passes"],
         "algorithmic_bytes_per_launch": algo_bytes,
-        "effective_per_query_GBps": round(float(n_local) * info["algo_code_bytes"] * nq /
+        "effective_per_query_GBps": round(float(n_local) * info["algo_code_bytes"] * nq_local /
                                           (tm["scan_ms"] * 1e-3) / 1e9, 1) if tm["scan_ms"] > 0 else 0.0,
         "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
                              "threshold_seed": round(tm["seed_ms"], 4), "merge": round(tm["merge_ms"], 4)},
@@ -284,7 +306,9 @@ def main():
             "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq, "k": k,
                        "bits": bits, "code_bytes": info["algo_code_bytes"],
                        "codes": "encoded" if real_codes else "uniform-random",
-                       "sharding": "rows, contiguous; RCCL all-gather of per-shard top-k" if world > 1 else "none"},
+                       "sharding": "none" if world == 1 else (
+                           "rows: contiguous shards, RCCL all-gather of per-shard top-k + merge" if mode == "rows"
+                           else "queries: codes replicated (fit HBM), disjoint query slices, RCCL all-gather of results")},
             "roofline": roofline, "cpu_baseline": cpu, "recall": recall,
         }
         print(json.dumps(out), flush=True)

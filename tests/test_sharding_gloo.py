@@ -81,6 +81,54 @@ def test_two_rank_shard_and_merge(oracle, N, k):
     assert ret.get(timeout=5) == "ok"
 
 
+def _worker_queries(rank, world, port, nq, k, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import make_case
+    from oracle import pyoracle as po
+    from vaq_amd import sharding
+    c = make_case(78, 32, [8] * 8, 2000, nq)
+    lo, hi = sharding.shard_bounds(nq, world, rank)
+    if hi > lo:
+        lab, dis = po.search(c["X"][lo:hi], c["cents"], c["codes"], k, eig=c["eig"])
+    else:
+        lab, dis = np.empty((0, k), np.int32), np.empty((0, k), np.float32)
+    gl, gd = sharding.gather_query_slices(torch.from_numpy(lab), torch.from_numpy(dis), nq)
+    full_l, full_d = po.search(c["X"], c["cents"], c["codes"], k, eig=c["eig"])
+    assert np.array_equal(gl.numpy(), full_l) and np.array_equal(gd.numpy(), full_d)
+    if rank == 0:
+        ret.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq", [7, 2, 1])
+def test_two_rank_query_sharding(oracle, nq):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_queries, args=(r, 2, port, nq, 20, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
+def test_choose_mode():
+    from vaq_amd.sharding import choose_mode
+    assert choose_mode(1_000_000, 8, 10_000, 8) == "queries"        # C2: 8 MB of codes, plenty of queries
+    assert choose_mode(1_000_000, 8, 100, 8) == "rows"              # too few queries to split
+    assert choose_mode(10**9, 16, 10_000, 8) == "queries"           # 16 GB still replicates on 288 GB parts
+    assert choose_mode(4 * 10**9, 16, 10_000, 8) == "rows"          # 64 GB: shard the rows
+    assert choose_mode(10**9, 16, 10_000, 8, "rows") == "rows"
+    assert choose_mode(10**6, 8, 10_000, 1) == "rows"
+
+
 def test_shard_bounds():
     from vaq_amd.sharding import shard_bounds
     for N in (0, 1, 7, 8, 9, 1000003):

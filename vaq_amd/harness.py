@@ -28,19 +28,28 @@ def _rotation(d: int, seed: int, device) -> torch.Tensor:
 
 
 def sift_like(n: int, d: int = 128, seed: int = SEED, stream: int = 0,
-              device="cpu", chunk: int = 1 << 20) -> torch.Tensor:
+              device="cpu", chunk: int = 1 << 20, clusters: int = 1024,
+              noise: float = 0.5) -> torch.Tensor:
     """'SIFT-shaped' vectors: d-dim, non-negative, integer-valued fp32 in
-    [0, 255], anisotropic: z ~ N(0, diag(lam)), lam_i ~ (i+1)^-1.2,
-    x = clip(round(26 + 40 * R z), 0, 255) with a fixed random rotation R."""
+    [0, 255] (about a quarter of the entries are 0, as in SIFT), anisotropic
+    and clustered: z = c_j + noise * e, with c_j one of `clusters` centres and
+    e ~ N(0, diag(lam)), c_j ~ N(0, diag(lam)), lam_i ~ (i+1)^-1.2;
+    x = clip(round(26 + 40 * R z), 0, 255) with a fixed random rotation R.
+    The mixture gives nearest neighbours real structure (8 x 8-bit PQ reaches
+    recall@100 of about 0.3 on 1M rows, like SIFT1M), which a single Gaussian
+    does not."""
     device = torch.device(device)
     lam = torch.arange(1, d + 1, dtype=torch.float64) ** -1.2
     lam = (lam * d / lam.sum()).to(torch.float32).to(device)
     R = _rotation(d, seed, device)
+    gc = torch.Generator(device="cpu").manual_seed(seed * 7 + 1)
+    C = (torch.randn(clusters, d, generator=gc, dtype=torch.float32)).to(device) * lam.sqrt()
     out = torch.empty((n, d), dtype=torch.float32, device=device)
     g = torch.Generator(device=device).manual_seed(seed * 1000003 + stream)
     for s in range(0, n, chunk):
         m = min(chunk, n - s)
-        z = torch.randn(m, d, generator=g, device=device, dtype=torch.float32) * lam.sqrt()
+        idx = torch.randint(0, clusters, (m,), generator=g, device=device)
+        z = C[idx] + noise * torch.randn(m, d, generator=g, device=device, dtype=torch.float32) * lam.sqrt()
         x = 26.0 + 40.0 * (z @ R.T)
         out[s:s + m] = x.round_().clamp_(0, 255)
     return out

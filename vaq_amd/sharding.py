@@ -13,6 +13,26 @@ from __future__ import annotations
 
 from typing import Callable, Tuple
 
+# Row-shard when one GPU should not (or cannot) hold the whole code array, or
+# when there are too few queries to give every GPU its own batch; otherwise
+# replicate the (small) code array and split the QUERIES: an MI355X has 288 GB
+# of HBM, so an 8 MB .. 16 GB code array is cheap to replicate, and query
+# sharding needs no merge at all (one all-gather of disjoint result rows).
+REPLICATE_MAX_BYTES = 32 << 30
+MIN_QUERIES_PER_RANK = 64
+
+
+def choose_mode(n_rows: int, code_bytes: int, nq: int, world: int, requested: str = "auto") -> str:
+    """'rows' (contiguous row shards + all-gather + merge) or
+    'queries' (replicated codes, disjoint query slices)."""
+    if requested in ("rows", "queries"):
+        return requested
+    if world == 1:
+        return "rows"
+    fits = n_rows * code_bytes <= REPLICATE_MAX_BYTES
+    enough = nq >= MIN_QUERIES_PER_RANK * world
+    return "queries" if (fits and enough) else "rows"
+
 
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row range [lo, hi) of `rank`: ceil(N/world) rows per shard,
@@ -37,3 +57,23 @@ def gather_and_merge(labels, dists, k: int, merge_fn: Callable, group=None):
     dist.all_gather_into_tensor(gl, labels.contiguous(), group=group)
     dist.all_gather_into_tensor(gd, dists.contiguous(), group=group)
     return merge_fn(gd.view(world, nq, k), gl.view(world, nq, k), k)
+
+
+def gather_query_slices(labels, dists, nq_total: int, group=None):
+    """Query sharding: this rank answered queries [lo, hi) = shard_bounds(nq_total,
+    world, rank) against ALL rows.  All-gathers the disjoint slices into the full
+    [nq_total, k] result on every rank (slices are padded to ceil(nq/world) rows)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = (nq_total + world - 1) // world
+    k = labels.shape[1]
+    pl = torch.full((per, k), -1, dtype=labels.dtype, device=labels.device)
+    pd = torch.zeros((per, k), dtype=dists.dtype, device=dists.device)
+    pl[: labels.shape[0]] = labels
+    pd[: dists.shape[0]] = dists
+    gl = torch.empty((world * per, k), dtype=labels.dtype, device=labels.device)
+    gd = torch.empty((world * per, k), dtype=dists.dtype, device=dists.device)
+    dist.all_gather_into_tensor(gl, pl, group=group)
+    dist.all_gather_into_tensor(gd, pd, group=group)
+    return gl[:nq_total], gd[:nq_total]
