@@ -152,7 +152,8 @@ def main():
             X = base_chunk(c)
             a, b = max(lo, c * GEN), min(hi, (c + 1) * GEN)
             xs = X[a - c * GEN: b - c * GEN]
-            codes[a - lo: b - lo] = harness.encode_torch(xs @ eig, cents)
+            # the product's own encoder (VAQ::encode on the GPU; projects with eig first)
+            codes[a - lo: b - lo] = v.encode_device(xs.contiguous(), projected=False)
             del X, xs
     else:
         g = torch.Generator(device=dev).manual_seed(harness.SEED + rank)

@@ -115,6 +115,27 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries_rowmajor, int nq,
 /* VAQ::ProjectOnEigenVectors (VAQ.hpp:198-201): out = X * real(eigvec). */
 int vaqhip_project(vaqhip_index *ix, const float *X_rowmajor, int64_t n, float *out);
 
+/* VAQ::encode / encodeImpl (VAQ.cpp:663-748): per subspace, argmin over centroids of the
+ * squared L2 to the row's sub-vector (strict <, first minimum wins).  codes_out is the
+ * reference's CodebookType, n x M uint16 row-major.  projected != 0: X is already in
+ * PCA space, which is what the reference's encode() expects (train() projects the
+ * dataset in place, VAQ.cpp:294); projected == 0 applies eigvec first. */
+int vaqhip_encode(vaqhip_index *ix, const float *X_rowmajor, int64_t n, int projected,
+                  uint16_t *codes_out);
+int vaqhip_encode_device(vaqhip_index *ix, const float *d_X, int64_t n, int projected,
+                         uint16_t *d_codes_out, void *stream);
+
+/* VAQ::refine (VAQ.cpp:849-876): exact squared L2 in the ORIGINAL space between each
+ * query and its R candidate rows of the raw dataset, k best by the same k-min rule.
+ * labels_in: nq x R (negative labels are skipped); R <= 2048.  The host form gathers
+ * the candidate rows from `dataset_rowmajor` (N x D, raw, unprojected) itself. */
+int vaqhip_refine(int device_id, const float *queries_rowmajor, int nq, int D,
+                  const float *dataset_rowmajor, int64_t N, const int32_t *labels_in, int R,
+                  int k, int32_t *labels_out, float *distances_out);
+int vaqhip_refine_device(int device_id, const float *d_queries, int nq, int D,
+                         const float *d_dataset, const int32_t *d_labels_in, int R, int k,
+                         int32_t *d_labels_out, float *d_distances_out, void *stream);
+
 /* Multi-GPU exchange step: after an all-gather of per-shard
  * results laid out [n_lists][nq][k] (labels already global), keep per query
  * the k smallest by (distance, label).  Device pointers.  The reference's

@@ -165,6 +165,31 @@ public:
     return ret;
   }
 
+  // VAQ::encode, VAQ.cpp:663-748: fills mCodebook from rows already in PCA
+  // space (as the reference expects after train()); projected = false applies
+  // mEigenVectors first.
+  template <class Mat> void encode(const Mat &XTrain, bool projected = true) {
+    const bool had = codes_set_;
+    codes_set_ = true;  // sync() must not try to upload the (empty) codebook first
+    try { sync(); } catch (...) { codes_set_ = had; throw; }
+    codes_set_ = false;
+    mCodebook = CodebookType((size_t)XTrain.rows(), (size_t)mHighestSubs());
+    check(vaqhip_encode(h_, XTrain.data(), (int64_t)XTrain.rows(), projected ? 1 : 0, mCodebook.data()));
+  }
+
+  // VAQ::refine, VAQ.hpp:104 / VAQ.cpp:849-876
+  template <class MatQ, class MatT>
+  LabelDistVecF refine(const MatQ &XTest, const LabelDistVecF &answersIn, const MatT &XTrain, const int k) {
+    const int nq = (int)XTest.rows();
+    const int R = nq ? (int)(answersIn.labels.size() / nq) : 0;
+    LabelDistVecF ret;
+    ret.labels.resize((size_t)k * nq);
+    ret.distances.resize((size_t)k * nq);
+    check(vaqhip_refine(mDevice, XTest.data(), nq, (int)XTest.cols(), XTrain.data(), (int64_t)XTrain.rows(),
+                        answersIn.labels.data(), R, k, ret.labels.data(), ret.distances.data()));
+    return ret;
+  }
+
   // Copy the search state out of a reference `VAQ` object (duck-typed: the
   // members of VAQ.hpp:51-75, Eigen matrices).  Instantiate only in a
   // translation unit that includes the reference's VAQ.hpp.

@@ -268,3 +268,82 @@ def test_seeded_multislice(vaqlib, oracle, bits):
                             what=f"seed={seed} slices={slices} qb={qb}")
     assert seen[0][2] > 1 and seen[0][3] > 0, seen     # auto plan: multi-slice and seeded
     assert seen[1][3] == 0 and seen[3][3] == 0, seen   # seeding off / single slice
+
+
+ENC_CASES = [
+    # D, bits
+    (128, [8] * 8),                       # L = 16
+    (128, [8] * 16),                      # L = 8
+    (128, [12, 10, 9, 8, 8, 7, 6, 4]),    # 4096 centroids stream through LDS in chunks
+    (128, [8] * 32),                      # L = 4
+    (128, [8] * 4),                       # L = 32
+    (48, [5, 3, 2, 1]),                   # L = 12: generic path, tiny codebooks
+    (8, [8] * 8),                         # L = 1
+]
+
+
+@pytest.mark.parametrize("D,bits", ENC_CASES, ids=[f"d{d}m{len(b)}" for d, b in ENC_CASES])
+def test_encode_matches_oracle(vaqlib, oracle, D, bits):
+    """VAQ::encode on the GPU == the oracle's restatement, code for code (same
+    sequential summation order, strict <)."""
+    c = make_case(801, D, bits, 10, 5)
+    rng = np.random.default_rng(5)
+    X = (rng.normal(size=(5000, D)) * 30).astype(np.float32)
+    L = D // len(bits)
+    if bits[0] >= 2:
+        c["cents"][0][3] = c["cents"][0][2]      # two identical centroids: the first must win
+    v = make_index(c)
+    Xp = oracle.project(X, c["eig"])
+    v.encode(X, projected=False)                  # GPU projection == oracle projection bit for bit
+    assert np.array_equal(v.mCodebook, oracle.encode(Xp, c["cents"]))
+    # plant (in PCA space) an exact copy of a centroid and an exact tie between two centroids
+    Xp[0, :L] = c["cents"][0][1]
+    Xp[1, :L] = c["cents"][0][2 if bits[0] >= 2 else 0]
+    want = oracle.encode(Xp, c["cents"])
+    v.encode(Xp, projected=True)
+    assert np.array_equal(v.mCodebook, want)
+    assert v.mCodebook[0, 0] == 1 and v.mCodebook[1, 0] == (2 if bits[0] >= 2 else 0)
+    import torch
+    got = v.encode_device(torch.from_numpy(Xp).cuda(), projected=True).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, want)
+
+
+def test_refine_matches_oracle(vaqlib, oracle):
+    import vaq_amd
+    rng = np.random.default_rng(9)
+    N, D, nq, R, k = 5000, 128, 12, 200, 100
+    Xt = rng.integers(0, 256, size=(N, D)).astype(np.float32)
+    Xt[100] = Xt[7]                                # duplicate rows: exactly equal distances
+    Xq = rng.integers(0, 256, size=(nq, D)).astype(np.float32)
+    cand = np.stack([rng.permutation(N)[:R] for _ in range(nq)]).astype(np.int32)
+    cand[0, :2] = [7, 100]
+    o_lab, o_dis = oracle.refine(Xq, Xt, cand, k)
+    v = vaq_amd.VaqHip()
+    ans = v.refine(Xq, vaq_amd.LabelDistVec(cand.ravel(), np.zeros(cand.size, np.float32)), Xt, k)
+    assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), o_lab, o_dis)
+    # unfilled candidates (-1) are skipped
+    cand2 = cand.copy()
+    cand2[:, 150:] = -1
+    ans2 = v.refine(Xq, vaq_amd.LabelDistVec(cand2.ravel(), np.zeros(cand.size, np.float32)), Xt, k)
+    o2_lab, o2_dis = oracle.refine(Xq, Xt, cand[:, :150], k)
+    assert_topk_matches(ans2.labels.reshape(nq, k), ans2.distances.reshape(nq, k), o2_lab, o2_dis)
+
+
+def test_search_then_refine_pipeline(vaqlib, oracle):
+    """demo_vaq.cpp:336-345: search with R candidates, refine to k against the
+    raw vectors; the GPU pipeline equals the oracle pipeline."""
+    import torch
+    from vaq_amd import harness
+    X = harness.sift_like(20000, 128, stream=1).numpy()
+    Q = harness.sift_like(16, 128, stream=2).numpy()
+    eig = harness.pca_eigenvectors(torch.from_numpy(X)).numpy()
+    cents = harness.train_codebooks(torch.from_numpy(X @ eig), [8] * 8, iters=5)
+    c = dict(bits=[8] * 8, cents=cents, eig=eig, codes=np.zeros((0, 8), np.uint16))
+    v = make_index(c)
+    v.encode(X, projected=False)
+    assert np.array_equal(v.mCodebook, oracle.encode(oracle.project(X, eig), cents))
+    ans = v.search(Q, 200)
+    fin = v.refine(Q, ans, X, 100)
+    o_l, o_d = oracle.search(Q, cents, v.mCodebook, 200, eig=eig)
+    o_rl, o_rd = oracle.refine(Q, X, o_l, 100)
+    assert_topk_matches(fin.labels.reshape(16, 100), fin.distances.reshape(16, 100), o_rl, o_rd)

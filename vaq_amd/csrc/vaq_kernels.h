@@ -72,6 +72,13 @@ hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,
                             float *lut, hipStream_t st);
 hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDesc *sub,
                              int lut_floats, int ksub, float *lut_ref, hipStream_t st);
+// VAQ::encodeImpl: Xp is n x D already in PCA space; codes is n x M uint16 row-major
+hipError_t launch_encode(const float *Xp, int64_t n, int D, int M, int L, const SubDesc *sub,
+                         const float *cent, uint16_t *codes, hipStream_t st);
+// VAQ::refine: exact re-rank of R (<= 2048) candidates per query
+hipError_t launch_refine(const float *Q, int nq, int D, const float *dataset, const float *rows,
+                         const int32_t *labels_in, int R, int k, int32_t *labels, float *dist,
+                         hipStream_t st);
 // dwords the packed layout needs for `rows` rows
 int64_t packed_words(int64_t rows, int M, int layout, int W);
 // Pack rows [row_begin, row_end) (codes_u16 points at row_begin; row_begin a

@@ -232,6 +232,93 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 }
 
 // ---------------------------------------------------------------------------
+// VAQ::encodeImpl, VAQ.cpp:728-748: per subspace, per row, argmin over codes of
+// (x_block - c_row).squaredNorm(), strict `<` so the first minimum wins.  The
+// reference leaves the summation order to Eigen's vectorised reduction; here
+// (and in the oracle) it is the sequential  dist = 0; dist += t*t  over the
+// subspace's dimensions, multiply and add unfused.
+// grid = (row tile of 256, subspace); one row per thread, its L values in
+// registers (LT = compile-time L) or read back from an LDS tile (LT = 0);
+// centroids stream through LDS in chunks of 256 (broadcast reads).
+// ---------------------------------------------------------------------------
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_CHUNK = 256;
+
+template <int LT>
+__global__ __launch_bounds__(ENC_THREADS) void encode_kernel(
+    const float *__restrict__ Xp, int64_t n, int D, int L, const SubDesc *__restrict__ sub,
+    const float *__restrict__ cent, int M, uint16_t *__restrict__ codes) {
+  extern __shared__ __attribute__((aligned(16))) float esm[];
+  const int tid = threadIdx.x;
+  const int s = blockIdx.y;
+  const SubDesc sd = sub[s];
+  const int64_t row = (int64_t)blockIdx.x * ENC_THREADS + tid;
+  const bool valid = row < n;
+  float *cs = esm;                                  // [ENC_CHUNK][L]
+  float *xs = esm + (size_t)ENC_CHUNK * L;          // [L][ENC_THREADS] (LT == 0 only)
+  float xr[LT > 0 ? LT : 1];
+  const float *xp = Xp + (valid ? row : 0) * D + (int64_t)s * L;
+  if (LT > 0) {
+#pragma unroll
+    for (int j = 0; j < LT; j++) xr[j] = xp[j];
+  } else {
+    for (int j = 0; j < L; j++) xs[j * ENC_THREADS + tid] = xp[j];
+  }
+  float bsf = FLT_MAX;
+  int best = 0;
+  const float *cg = cent + sd.cent_off;
+  for (int c0 = 0; c0 < sd.ncent; c0 += ENC_CHUNK) {
+    const int cn = sd.ncent - c0 < ENC_CHUNK ? sd.ncent - c0 : ENC_CHUNK;
+    __syncthreads();
+    for (int e = tid; e < cn * L; e += ENC_THREADS) cs[e] = cg[(size_t)c0 * L + e];
+    __syncthreads();
+    for (int c = 0; c < cn; c++) {
+      const float *cr = cs + c * (LT > 0 ? LT : L);
+      float dist = 0.0f;
+      if (LT > 0) {
+#pragma unroll
+        for (int j = 0; j < LT; j++) {
+          const float t = xr[j] - cr[j];
+          dist += t * t;
+        }
+      } else {
+        for (int j = 0; j < L; j++) {
+          const float t = xs[j * ENC_THREADS + tid] - cr[j];
+          dist += t * t;
+        }
+      }
+      if (dist < bsf) {
+        bsf = dist;
+        best = c0 + c;
+      }
+    }
+  }
+  if (valid) codes[row * M + s] = (uint16_t)best;
+}
+
+hipError_t launch_encode(const float *Xp, int64_t n, int D, int M, int L, const SubDesc *sub,
+                         const float *cent, uint16_t *codes, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const dim3 grid((unsigned)((n + ENC_THREADS - 1) / ENC_THREADS), M);
+  const size_t lds_reg = (size_t)ENC_CHUNK * L * sizeof(float);
+  switch (L) {
+  case 4:  hipLaunchKernelGGL(encode_kernel<4>, grid, dim3(ENC_THREADS), lds_reg, st, Xp, n, D, L, sub, cent, M, codes); break;
+  case 8:  hipLaunchKernelGGL(encode_kernel<8>, grid, dim3(ENC_THREADS), lds_reg, st, Xp, n, D, L, sub, cent, M, codes); break;
+  case 16: hipLaunchKernelGGL(encode_kernel<16>, grid, dim3(ENC_THREADS), lds_reg, st, Xp, n, D, L, sub, cent, M, codes); break;
+  case 32: hipLaunchKernelGGL(encode_kernel<32>, grid, dim3(ENC_THREADS), lds_reg, st, Xp, n, D, L, sub, cent, M, codes); break;
+  default: {
+    const size_t lds = lds_reg + (size_t)L * ENC_THREADS * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(encode_kernel<0>, grid, dim3(ENC_THREADS), lds, st, Xp, n, D, L, sub, cent, M, codes);
+  }
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Bitonic networks on (distance, id) pairs in LDS, ascending by (distance, id).
 // WG = false: one wavefront, no barriers (LDS is in-order per wave);
 // WG = true : the whole workgroup with __syncthreads.
@@ -1073,6 +1160,65 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
   }
   if (thr_out && tid == 0 && kept >= k && si[k - 1] != ID_SENTINEL)
     atomicMin(&thr_out[q], __builtin_bit_cast(unsigned, sd[k - 1]));
+}
+
+// ---------------------------------------------------------------------------
+// VAQ::refine, VAQ.cpp:849-876: exact squared L2 between the raw query and the
+// raw dataset row of each of R candidates, then the same k-min.  The
+// reference's squaredNorm order is Eigen's; here (and in the oracle) it is the
+// sequential  dist = 0; dist += t*t.  One workgroup per query: thread t owns
+// candidates t, t+256, ...; then a bitonic sort of the R (<= 2048) pairs.
+// rows == nullptr: candidate vectors are read from `dataset` by label;
+// otherwise `rows` holds them gathered as [nq][R][D].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MERGE_THREADS) void refine_kernel(
+    const float *__restrict__ Q, int D, const float *__restrict__ dataset,
+    const float *__restrict__ rows, const int32_t *__restrict__ labels_in, int R, int k,
+    int32_t *__restrict__ labels, float *__restrict__ dist) {
+  __shared__ float sd[MERGE_CAP];
+  __shared__ int si[MERGE_CAP];
+  extern __shared__ float qs[];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < D; j += MERGE_THREADS) qs[j] = Q[(size_t)q * D + j];
+  int P = 2;
+  while (P < R) P <<= 1;
+  __syncthreads();
+  for (int i = tid; i < P; i += MERGE_THREADS) {
+    float d = INFINITY;
+    int id = ID_SENTINEL;
+    if (i < R) {
+      const int lab = labels_in[(size_t)q * R + i];
+      if (lab >= 0) {
+        const float *y = rows ? rows + ((size_t)q * R + i) * D : dataset + (size_t)lab * D;
+        float acc = 0.0f;
+        for (int j = 0; j < D; j++) {
+          const float t = qs[j] - y[j];
+          acc += t * t;
+        }
+        // heap admission rule (VAQ.cpp:867): heap_top > dist with the neutral FLT_MAX
+        if (acc < FLT_MAX) { d = acc; id = lab; }
+      }
+    }
+    sd[i] = d;
+    si[i] = id;
+  }
+  __syncthreads();
+  bitonic_sort<true>(sd, si, P, tid, MERGE_THREADS);
+  for (int i = tid; i < k; i += MERGE_THREADS) {
+    const bool ok = i < P && si[i] != ID_SENTINEL;
+    labels[(size_t)q * k + i] = ok ? si[i] : -1;
+    dist[(size_t)q * k + i] = ok ? sd[i] : FLT_MAX;
+  }
+}
+
+hipError_t launch_refine(const float *Q, int nq, int D, const float *dataset, const float *rows,
+                         const int32_t *labels_in, int R, int k, int32_t *labels, float *dist,
+                         hipStream_t st) {
+  if (nq == 0) return hipSuccess;
+  if (R > MERGE_CAP || R < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(refine_kernel, dim3(nq), dim3(MERGE_THREADS), D * sizeof(float), st, Q, D, dataset,
+                     rows, labels_in, R, k, labels, dist);
+  return hipGetLastError();
 }
 
 size_t merge_scratch_elems(int n_lists, int nq, int k) {

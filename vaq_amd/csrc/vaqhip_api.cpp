@@ -609,6 +609,115 @@ int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists, const int
   return VAQHIP_OK;
 }
 
+int vaqhip_encode_device(vaqhip_index *ix, const float *d_X, int64_t n, int projected,
+                         uint16_t *d_codes, void *stream) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (n < 0 || (n > 0 && (!d_X || !d_codes))) return fail(VAQHIP_EINVAL, "bad arguments");
+  if (n == 0) return VAQHIP_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool do_project = !projected && ix->has_eig;
+  const int64_t chunk = std::min<int64_t>(n, 1 << 20);
+  if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  for (int64_t r = 0; r < n; r += chunk) {
+    const int64_t m = std::min(chunk, n - r);
+    const float *xp = d_X + r * ix->D;
+    if (do_project) {
+      HIP_TRY(vaq::launch_project(xp, m, ix->D, ix->d_eig.as<float>(), ix->w_qproj.as<float>(), st));
+      xp = ix->w_qproj.as<float>();
+    }
+    HIP_TRY(vaq::launch_encode(xp, m, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
+                               ix->d_cent.as<float>(), d_codes + r * ix->M, st));
+  }
+  return VAQHIP_OK;
+}
+
+int vaqhip_encode(vaqhip_index *ix, const float *X, int64_t n, int projected, uint16_t *codes) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (n < 0 || (n > 0 && (!X || !codes))) return fail(VAQHIP_EINVAL, "bad arguments");
+  if (n == 0) return VAQHIP_OK;
+  const int64_t chunk = std::min<int64_t>(n, 1 << 20);
+  {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+    HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
+    HIP_TRY(ix->w_stage.ensure((size_t)chunk * ix->M * sizeof(uint16_t)));
+  }
+  for (int64_t r = 0; r < n; r += chunk) {
+    const int64_t m = std::min(chunk, n - r);
+    {
+      DeviceGuard g(ix->device);
+      HIP_TRY(hipMemcpyAsync(ix->w_q.p, X + r * ix->D, (size_t)m * ix->D * sizeof(float),
+                             hipMemcpyHostToDevice, ix->stream));
+    }
+    int rc = vaqhip_encode_device(ix, ix->w_q.as<float>(), m, projected, ix->w_stage.as<uint16_t>(),
+                                  ix->stream);
+    if (rc) return rc;
+    DeviceGuard g(ix->device);
+    HIP_TRY(hipMemcpyAsync(codes + r * ix->M, ix->w_stage.p, (size_t)m * ix->M * sizeof(uint16_t),
+                           hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+  }
+  return VAQHIP_OK;
+}
+
+int vaqhip_refine_device(int device_id, const float *d_queries, int nq, int D, const float *d_dataset,
+                         const int32_t *d_labels_in, int R, int k, int32_t *d_labels_out,
+                         float *d_dist_out, void *stream) {
+  if (nq < 0 || D <= 0 || R <= 0 || k <= 0) return fail(VAQHIP_EINVAL, "bad sizes");
+  if (R > 2048 || k > R) return fail(VAQHIP_EUNSUPPORTED, "need k <= R <= 2048 (R=%d k=%d)", R, k);
+  if (nq == 0) return VAQHIP_OK;
+  if (!d_queries || !d_dataset || !d_labels_in || !d_labels_out || !d_dist_out)
+    return fail(VAQHIP_EINVAL, "null pointer");
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
+  HIP_TRY(vaq::launch_refine(d_queries, nq, D, d_dataset, nullptr, d_labels_in, R, k, d_labels_out,
+                             d_dist_out, static_cast<hipStream_t>(stream)));
+  return VAQHIP_OK;
+}
+
+int vaqhip_refine(int device_id, const float *queries, int nq, int D, const float *dataset, int64_t N,
+                  const int32_t *labels_in, int R, int k, int32_t *labels_out, float *dist_out) {
+  if (nq < 0 || D <= 0 || R <= 0 || k <= 0 || N < 0) return fail(VAQHIP_EINVAL, "bad sizes");
+  if (R > 2048 || k > R) return fail(VAQHIP_EUNSUPPORTED, "need k <= R <= 2048 (R=%d k=%d)", R, k);
+  if (nq == 0) return VAQHIP_OK;
+  if (!queries || !dataset || !labels_in || !labels_out || !dist_out) return fail(VAQHIP_EINVAL, "null pointer");
+  DeviceGuard g(device_id);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed (no CPU path)", device_id);
+  // gather the candidate rows on the host, re-rank on the GPU, in chunks of queries
+  const size_t per_q = (size_t)R * D;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)nq, ((size_t)256 << 20) / (per_q * 4)));
+  DevBuf d_q, d_rows, d_lab, d_ol, d_od;
+  HIP_TRY(d_q.ensure((size_t)chunk * D * 4));
+  HIP_TRY(d_rows.ensure((size_t)chunk * per_q * 4));
+  HIP_TRY(d_lab.ensure((size_t)chunk * R * 4));
+  HIP_TRY(d_ol.ensure((size_t)chunk * k * 4));
+  HIP_TRY(d_od.ensure((size_t)chunk * k * 4));
+  std::vector<float> rows((size_t)chunk * per_q);
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int n = std::min(chunk, nq - q0);
+    for (int q = 0; q < n; q++)
+      for (int i = 0; i < R; i++) {
+        const int32_t lab = labels_in[(size_t)(q0 + q) * R + i];
+        float *dst = rows.data() + ((size_t)q * R + i) * D;
+        if (lab >= 0 && (int64_t)lab < N) std::memcpy(dst, dataset + (size_t)lab * D, (size_t)D * 4);
+        else if (lab >= 0) return fail(VAQHIP_EINVAL, "label %d outside the dataset", lab);
+        else std::memset(dst, 0, (size_t)D * 4);
+      }
+    HIP_TRY(hipMemcpy(d_q.p, queries + (size_t)q0 * D, (size_t)n * D * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_rows.p, rows.data(), (size_t)n * per_q * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_lab.p, labels_in + (size_t)q0 * R, (size_t)n * R * 4, hipMemcpyHostToDevice));
+    HIP_TRY(vaq::launch_refine(d_q.as<float>(), n, D, nullptr, d_rows.as<float>(), d_lab.as<int32_t>(), R, k,
+                               d_ol.as<int32_t>(), d_od.as<float>(), nullptr));
+    HIP_TRY(hipMemcpy(labels_out + (size_t)q0 * k, d_ol.p, (size_t)n * k * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dist_out + (size_t)q0 * k, d_od.p, (size_t)n * k * 4, hipMemcpyDeviceToHost));
+  }
+  return VAQHIP_OK;
+}
+
 int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out) {
   if (!ix || !out) return fail(VAQHIP_EINVAL, "null pointer");
   out->D = ix->D;

@@ -222,6 +222,46 @@ class VaqHip:
             C.c_void_p(labels.data_ptr()), C.c_void_p(dists.data_ptr()), C.c_void_p(st)))
         return labels, dists
 
+    # ----------------------------------------------------- encode / refine --
+    def encode(self, XTrain: np.ndarray, projected: bool = True) -> None:
+        """VAQ::encode (VAQ.cpp:663-748): fills mCodebook (N x M uint16).  Like
+        the reference it expects rows already in PCA space (train() projects the
+        dataset in place); projected=False applies mEigenVectors first."""
+        self._ensure_index()
+        X = np.ascontiguousarray(XTrain, dtype=np.float32)
+        codes = np.empty((X.shape[0], len(self.mBitsAlloc)), np.uint16)
+        _lib.check(_lib.load().vaqhip_encode(self._h, _ptr(X), X.shape[0], 1 if projected else 0,
+                                             _ptr(codes)))
+        self.mCodebook = codes
+
+    def encode_device(self, d_X, projected: bool = True):
+        """torch CUDA tensor in, N x M int16 CUDA tensor (uint16 codes) out, on
+        torch's current stream."""
+        import torch
+        self._ensure_index()
+        x = d_X.contiguous()
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[1] == self.mTotalDim
+        codes = torch.empty((x.shape[0], len(self.mBitsAlloc)), dtype=torch.int16, device=x.device)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(_lib.load().vaqhip_encode_device(self._h, C.c_void_p(x.data_ptr()), x.shape[0],
+                                                    1 if projected else 0, C.c_void_p(codes.data_ptr()),
+                                                    C.c_void_p(st)))
+        return codes
+
+    def refine(self, XTest: np.ndarray, answersIn: LabelDistVec, XTrain: np.ndarray, k: int) -> LabelDistVec:
+        """VAQ::refine (VAQ.cpp:849-876): exact re-rank of the candidates in
+        answersIn against the raw dataset XTrain."""
+        _lib.load()
+        Xq = np.ascontiguousarray(XTest, dtype=np.float32)
+        Xt = np.ascontiguousarray(XTrain, dtype=np.float32)
+        nq = Xq.shape[0]
+        lab = np.ascontiguousarray(answersIn.labels, dtype=np.int32)
+        R = lab.size // max(nq, 1)
+        ret = LabelDistVec(np.empty(nq * k, np.int32), np.empty(nq * k, np.float32))
+        _lib.check(_lib.load().vaqhip_refine(self.device, _ptr(Xq), nq, Xq.shape[1], _ptr(Xt), Xt.shape[0],
+                                             _ptr(lab), R, k, _ptr(ret.labels), _ptr(ret.distances)))
+        return ret
+
     # -------------------------------------------------------- test hooks ---
     def build_lut(self, XTest: np.ndarray, projected: bool = False) -> np.ndarray:
         """CreateLUT for every query in the reference's LUTType layout:
