@@ -44,6 +44,9 @@ struct ScanParams {
   int M;                  // subspaces
   int W;                  // dwords per row (bit-packed layout)
   const SubDesc *sub;     // [M]
+  const uint32_t *perm;   // [n_rows] sorted row -> original row (labels), or nullptr = identity
+  const int *bucket_start;// [n_buckets + 1] first sorted row of each subspace-0 code
+  int n_buckets;          // 1 << bits[0]
   const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
   const float *lut;       // [nq][lut_floats]
   int lut_floats;
@@ -83,9 +86,15 @@ hipError_t launch_refine(const float *Q, int nq, int D, const float *dataset, co
 int64_t packed_words(int64_t rows, int M, int layout, int W);
 // Pack rows [row_begin, row_end) (codes_u16 points at row_begin; row_begin a
 // multiple of 64) and zero-fill the packed words up to out_row_end.
+// perm (optional): packed row r is source row perm[r] (the bucketed order)
 hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64_t row_end,
                              int64_t out_row_end, int M, int layout, int W, const SubDesc *sub,
-                             uint32_t *out, hipStream_t st);
+                             const uint32_t *perm, uint32_t *out, hipStream_t st);
+// Stable sort of rows by their subspace-0 code: d_perm[n] (sorted row -> original
+// row) and d_bucket_start[(1<<bits0)+1] (first sorted row of each code that
+// occurs, -1 otherwise; the caller back-fills).  Synchronises the stream.
+hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, uint32_t *d_perm,
+                              int *d_bucket_start, hipStream_t st);
 // LDS geometry of a scan workgroup for top-k = k
 void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap);
 // bytes of LDS a scan workgroup of `nwaves` wavefronts needs

@@ -14,6 +14,9 @@
 //   merge_kernel        heap_reorder's sorted output         utils/Heap.hpp:322-349
 #include "vaq_kernels.h"
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <float.h>
 #include <limits.h>
 
@@ -183,8 +186,8 @@ hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDe
 // ---------------------------------------------------------------------------
 __global__ void pack_codes_kernel(const uint16_t *__restrict__ in, int64_t row_begin,
                                   int64_t row_end, int M, int layout, int W,
-                                  const SubDesc *__restrict__ sub, uint32_t *__restrict__ out,
-                                  int64_t t_begin, int64_t t_end) {
+                                  const SubDesc *__restrict__ sub, const uint32_t *__restrict__ perm,
+                                  uint32_t *__restrict__ out, int64_t t_begin, int64_t t_end) {
   const int64_t t = t_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= t_end) return;
   uint32_t v = 0;
@@ -193,7 +196,7 @@ __global__ void pack_codes_kernel(const uint16_t *__restrict__ in, int64_t row_b
     const int64_t r = t / wpr;
     const int w = (int)(t - r * wpr);
     if (r >= row_begin && r < row_end) {
-      const uint16_t *c = in + (r - row_begin) * M + w * 4;
+      const uint16_t *c = in + ((perm ? (int64_t)perm[r] : r) - row_begin) * M + w * 4;
       v = (uint32_t)(c[0] & 0xff) | ((uint32_t)(c[1] & 0xff) << 8) |
           ((uint32_t)(c[2] & 0xff) << 16) | ((uint32_t)(c[3] & 0xff) << 24);
     }
@@ -203,9 +206,10 @@ __global__ void pack_codes_kernel(const uint16_t *__restrict__ in, int64_t row_b
     const int w = rem / TILE_ROWS;
     const int64_t r = tile * TILE_ROWS + (rem % TILE_ROWS);
     if (r >= row_begin && r < row_end) {
+      const int64_t src = (perm ? (int64_t)perm[r] : r) - row_begin;
       for (int s = 0; s < M; s++) {
         const SubDesc sd = sub[s];
-        const uint32_t code = (uint32_t)in[(r - row_begin) * M + s] & (uint32_t)(sd.ncent - 1);
+        const uint32_t code = (uint32_t)in[src * M + s] & (uint32_t)(sd.ncent - 1);
         if (sd.word == w) v |= code << sd.shift;
         else if (sd.word + 1 == w && sd.shift + sd.bits > 32) v |= code >> (32 - sd.shift);
       }
@@ -221,14 +225,76 @@ int64_t packed_words(int64_t rows, int M, int layout, int W) {
 
 hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64_t row_end,
                              int64_t out_row_end, int M, int layout, int W, const SubDesc *sub,
-                             uint32_t *out, hipStream_t st) {
+                             const uint32_t *perm, uint32_t *out, hipStream_t st) {
   const int64_t t_begin = packed_words(row_begin, M, layout, W);
   const int64_t t_end = packed_words(out_row_end, M, layout, W);
   if (t_end <= t_begin) return hipSuccess;
   const int64_t blocks = (t_end - t_begin + 255) / 256;
   hipLaunchKernelGGL(pack_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, codes_u16,
-                     row_begin, row_end, M, layout, W, sub, out, t_begin, t_end);
+                     row_begin, row_end, M, layout, W, sub, perm, out, t_begin, t_end);
   return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Bucketed row order.  The index stores rows stably sorted by the code of
+// subspace 0 -- after PCA the highest-variance subspace -- so that all rows of
+// a bucket share the first LUT term: the scan reads that term once per bucket
+// (wave-uniform) and skips a whole bucket, without touching its codes, when the
+// term alone already exceeds the threshold of every query in the batch (the
+// bucket-level form of VAQ::searchEarlyAbandon's test, VAQ.cpp:1708).
+//   perm[r]          original row of sorted row r (labels are original rows)
+//   bucket_start[b]  first sorted row whose code 0 is >= b  (b = 0 .. K0)
+// ---------------------------------------------------------------------------
+__global__ void first_code_keys_kernel(const uint16_t *__restrict__ codes, int64_t n, int M,
+                                       unsigned mask, uint16_t *__restrict__ keys,
+                                       uint32_t *__restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (uint16_t)(codes[i * M] & mask);
+  idx[i] = (uint32_t)i;
+}
+
+// start[b] = first i with keys[i] == b, for the codes that occur (others stay -1)
+__global__ void bucket_bounds_kernel(const uint16_t *__restrict__ keys, int64_t n, int *__restrict__ start) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0 || keys[i] != keys[i - 1]) start[keys[i]] = (int)i;
+}
+
+hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, uint32_t *d_perm,
+                              int *d_bucket_start, hipStream_t st) {
+  const int K0 = 1 << bits0;
+  hipError_t e = hipMemsetAsync(d_bucket_start, 0xff, (size_t)(K0 + 1) * sizeof(int), st);
+  if (e != hipSuccess || n == 0) return e;
+  uint16_t *keys_in = nullptr, *keys_out = nullptr;
+  uint32_t *idx_in = nullptr;
+  void *temp = nullptr;
+  size_t temp_bytes = 0;
+  auto cleanup = [&]() {
+    (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(idx_in); (void)hipFree(temp);
+  };
+  if ((e = hipMalloc(&keys_in, (size_t)n * 2)) != hipSuccess || (e = hipMalloc(&keys_out, (size_t)n * 2)) != hipSuccess ||
+      (e = hipMalloc(&idx_in, (size_t)n * 4)) != hipSuccess) {
+    cleanup();
+    return e;
+  }
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(first_code_keys_kernel, dim3(blocks), dim3(256), 0, st, d_codes, n, M,
+                     (unsigned)(K0 - 1), keys_in, idx_in);
+  // stable LSD radix sort on the b0 key bits: equal codes keep ascending original rows
+  e = rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
+                                (unsigned)bits0, st);
+  if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
+  if (e == hipSuccess)
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
+                                  (unsigned)bits0, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bucket_bounds_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, d_bucket_start);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  cleanup();
+  return e;
 }
 
 // ---------------------------------------------------------------------------
@@ -497,6 +563,7 @@ template <int QB> struct ScanCtx {
   int k, kp, ccap;
   bool multi_slice;
   unsigned *g_thr;
+  const uint32_t *perm;
 
   __device__ __forceinline__ void setup(unsigned char *smem, const ScanParams &p, int lut_entries,
                                         int qbatch, int tid, int nthreads) {
@@ -510,6 +577,7 @@ template <int QB> struct ScanCtx {
     qcnt = 0;
     multi_slice = p.share_thr != 0;
     g_thr = p.g_thr;
+    perm = p.perm;
     lut = reinterpret_cast<LT *>(smem);
     size_t off = ((size_t)lut_entries * sizeof(LT) + 15) & ~(size_t)15;
     const size_t sb = (sel_bytes(p.kp, p.ccap) + 15) & ~(size_t)15;
@@ -584,13 +652,16 @@ template <int QB> struct ScanCtx {
     return a;
   }
 
-  // final distances of up to 64 rows (one per lane): admit those strictly
-  // below the query's threshold
-  __device__ __forceinline__ void admit(const float (&dist)[QB], int rid, bool ok) {
+  // final distances of up to 64 rows (one per lane, `srow` = row in the index's
+  // bucketed order): admit those strictly below the query's threshold.  Labels
+  // are ORIGINAL rows (perm), so ties break as the contract says.
+  __device__ __forceinline__ void admit(const float (&dist)[QB], int srow, bool ok) {
+    // cheap pre-test against the cached (never tighter than exact) thresholds
+    if (__ballot(ok && survives(dist)) == 0ull) return;
+    const int rid = (ok && survives(dist) && perm) ? (int)perm[srow] : srow;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       const float dq = dist[q];
-      // cheap pre-test against the cached (never tighter than exact) threshold
       if (__ballot(ok && !(dq > thr_d[q])) == 0ull) continue;
       const SelView &v = sel[q];
       sel_lock(v, lane);
@@ -785,21 +856,19 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams
     finish(cw, acc, rid, ok);
   };
 
-  Item pf[PREFETCH];
+  if (EA == EA_NONE) {
+    Item pf[PREFETCH];
 #pragma unroll
-  for (int i = 0; i < PREFETCH; i++)
-    if (i < n_steps) pf[i].load(p.codes, item0 + (int64_t)i * step_items);
-
-  for (int st = 0; st < n_steps; st++) {
-    const Item cur = pf[0];
+    for (int i = 0; i < PREFETCH; i++)
+      if (i < n_steps) pf[i].load(p.codes, item0 + (int64_t)i * step_items);
+    for (int st = 0; st < n_steps; st++) {
+      const Item cur = pf[0];
 #pragma unroll
-    for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
-    if (st + PREFETCH < n_steps)
-      pf[PREFETCH - 1].load(p.codes, item0 + (int64_t)(st + PREFETCH) * step_items);
-    cx.refresh(st);
-
-    const int row0 = (int)(item0 + (int64_t)st * step_items) * Item::ROWS;
-    if (!EA) {
+      for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
+      if (st + PREFETCH < n_steps)
+        pf[PREFETCH - 1].load(p.codes, item0 + (int64_t)(st + PREFETCH) * step_items);
+      cx.refresh(st);
+      const int row0 = (int)(item0 + (int64_t)st * step_items) * Item::ROWS;
 #pragma unroll
       for (int r = 0; r < Item::ROWS; r++) {
         uint32_t cw[WPR];
@@ -809,34 +878,86 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams
         group_sum(cw[0], 0, 0, 4, acc);  // dist = 0; dist += dism
         finish(cw, acc, row0 + r, row0 + r < r1);
       }
-    } else {
-      // A: every row of the item, all lanes
-      float part[Item::ROWS][QB];
-      bool alive[Item::ROWS];
-#pragma unroll
-      for (int r = 0; r < Item::ROWS; r++) group_sum(cur.word(r, 0), 0, 0, PHASE_A_SUBS, part[r]);
-#pragma unroll
-      for (int r = 0; r < Item::ROWS; r++) alive[r] = (row0 + r < r1) && cx.survives(part[r]);
-      // A2 + Q per row
-#pragma unroll
-      for (int r = 0; r < Item::ROWS; r++) {
-        bool live = alive[r];
-        if (live) {
-          group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
-          live = cx.survives(part[r]);
-        }
-        if (EA == EA_QUEUE) {
-          cx.push(live, row0 + r, part[r]);
-        } else {
-          // EA_INPLACE: the live lanes finish their rows where they stand
-          uint32_t cw[WPR];
-#pragma unroll
-          for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
-          finish(cw, part[r], row0 + r, live);
-        }
+    }
+  } else {
+    // Early abandon over the bucketed row order: each wave walks a contiguous
+    // part of the slice bucket by bucket (all rows of a bucket share code 0).
+    constexpr int WSTEP = 64 * Item::ROWS;  // rows per wave step
+    const int per_wave = ((r1 - r0 + cx.nwaves * WSTEP - 1) / (cx.nwaves * WSTEP)) * WSTEP;
+    const int w0 = r0 + wave * per_wave;
+    const int w1 = (w0 + per_wave < r1) ? w0 + per_wave : r1;
+    const int *__restrict__ bstart = p.bucket_start;
+    if (w0 < w1) {
+      int lo = 0, hi = p.n_buckets;  // largest b with bstart[b] <= w0
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bstart[mid] <= w0) lo = mid; else hi = mid;
       }
-      if (EA == EA_QUEUE)
-        while (cx.qcnt >= 64) drain(64);
+      int b = lo, pos = w0, stepno = 0;
+      while (pos < w1) {
+        int be = bstart[b + 1];
+        if (be > w1) be = w1;
+        if (be > pos) {
+          // the bucket's first term, dism = l0, is wave-uniform
+          const LT l0v = lut[b];
+          float l0[QB];
+#pragma unroll
+          for (int q = 0; q < QB; q++)
+            l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+          if (cx.survives(l0)) {  // otherwise no row of the bucket can be admitted: skip its codes
+            const int base0 = pos & ~(WSTEP - 1);
+            const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
+            Item pf[PREFETCH];
+#pragma unroll
+            for (int i = 0; i < PREFETCH; i++)
+              if (i < nst) pf[i].load(p.codes, (int64_t)((base0 + i * WSTEP) / Item::ROWS) + lane);
+            for (int t = 0; t < nst; t++) {
+              const Item cur = pf[0];
+#pragma unroll
+              for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
+              if (t + PREFETCH < nst)
+                pf[PREFETCH - 1].load(p.codes, (int64_t)((base0 + (t + PREFETCH) * WSTEP) / Item::ROWS) + lane);
+              const int base = base0 + t * WSTEP;
+              cx.refresh(stepno++);
+              const int row0 = base + lane * Item::ROWS;
+              // A: dism = l0; dism += l1, every row of the item, all lanes
+              float part[Item::ROWS][QB];
+              bool alive[Item::ROWS];
+#pragma unroll
+              for (int r = 0; r < Item::ROWS; r++) {
+#pragma unroll
+                for (int q = 0; q < QB; q++) part[r][q] = l0[q];
+                group_sum(cur.word(r, 0), 0, 1, PHASE_A_SUBS, part[r]);
+              }
+#pragma unroll
+              for (int r = 0; r < Item::ROWS; r++)
+                alive[r] = (row0 + r >= pos) && (row0 + r < be) && cx.survives(part[r]);
+              // A2 + Q per row
+#pragma unroll
+              for (int r = 0; r < Item::ROWS; r++) {
+                bool live = alive[r];
+                if (live) {
+                  group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
+                  live = cx.survives(part[r]);
+                }
+                if (EA == EA_QUEUE) {
+                  cx.push(live, row0 + r, part[r]);
+                } else {
+                  // EA_INPLACE: the live lanes finish their rows where they stand
+                  uint32_t cw[WPR];
+#pragma unroll
+                  for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
+                  finish(cw, part[r], row0 + r, live);
+                }
+              }
+              if (EA == EA_QUEUE)
+                while (cx.qcnt >= 64) drain(64);
+            }
+          }
+          pos = be;
+        }
+        b++;
+      }
     }
   }
   if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);
@@ -935,84 +1056,118 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
     cx.admit(acc, rid, alive);
   };
 
-  Item pf[PREFETCH];
+  // the rest of a row's chain from the words the lane holds (subspaces >= s_from)
+  auto tail_inplace = [&](const Item &it, int s_from, float (&acc)[QB], float (&dism)[QB], bool alive,
+                          const bool ea) -> bool {
+    int s = s_from;
 #pragma unroll
-  for (int i = 0; i < PREFETCH; i++)
-    if (i < n_steps) pf[i].load(p.codes, tile0 + (int64_t)i * nwaves, lane);
-
-  for (int st = 0; st < n_steps; st++) {
-    const Item cur = pf[0];
-#pragma unroll
-    for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
-    if (st + PREFETCH < n_steps)
-      pf[PREFETCH - 1].load(p.codes, tile0 + (int64_t)(st + PREFETCH) * nwaves, lane);
-    cx.refresh(st);
-
-    const int row = (int)(tile0 + (int64_t)st * nwaves) * TILE_ROWS + lane;
-    const bool valid = row < r1;
-    float acc[QB], dism[QB];
-#pragma unroll
-    for (int q = 0; q < QB; q++) { acc[q] = 0.0f; dism[q] = 0.0f; }
-    if (EA) {
-      const uint32_t w0 = cur.w[0];
-      const uint32_t w1 = W > 1 ? cur.w[W > 1 ? 1 : 0] : 0u;
-      // A: fields 0 and 1 (always inside dword 0)
-      const SubDesc s0 = sub[0], s1 = sub[1];
-      chain(0, lut[s0.lut_off + (w0 & (unsigned)(s0.ncent - 1))], acc, dism);
-      chain(1, lut[s1.lut_off + ((w0 >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
-      bool live = valid && cx.survives(dism);
-      if (live) {
-        // A2: fields 2 and 3 (dwords 0..1) complete the first group
-        const SubDesc s2 = sub[2], s3 = sub[3];
-        const uint32_t c2 = (s2.word == 0 ? __builtin_amdgcn_alignbit(w1, w0, (unsigned)s2.shift)
-                                          : (w1 >> s2.shift)) & (unsigned)(s2.ncent - 1);
-        const uint32_t c3 = (s3.word == 0 ? __builtin_amdgcn_alignbit(w1, w0, (unsigned)s3.shift)
-                                          : (w1 >> s3.shift)) & (unsigned)(s3.ncent - 1);
-        chain(2, lut[s2.lut_off + c2], acc, dism);
-        chain(3, lut[s3.lut_off + c3], acc, dism);
-        live = cx.survives(acc);
-      }
-      if (EA == EA_QUEUE) {
-        cx.push(live, row, acc);
-        while (cx.qcnt >= 64) drain(64);
-      } else {
-        // EA_INPLACE: the live lanes finish their rows from the words they hold
-        bool alive = live;
-        int s = 4;
-#pragma unroll
-        for (int wi = 0; wi < W; wi++) {
-          const uint32_t lo = cur.w[wi];
-          const uint32_t hi = (wi + 1 < W) ? cur.w[wi + 1 < W ? wi + 1 : wi] : 0u;
-          const int s_end = first_sub[wi + 1];
-          if (s < first_sub[wi]) s = first_sub[wi];
-          for (; s < s_end; s++) {
-            if (s < 4) continue;
-            const SubDesc sd = sub[s];
-            if (alive) {
-              const uint32_t c =
-                  __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
-              chain(s, lut[sd.lut_off + c], acc, dism);
-              if ((s & 3) == 3) alive = cx.survives(acc);
-            }
-          }
-        }
-        cx.admit(acc, row, alive);
-      }
-    } else {
-      int s = 0;
-#pragma unroll
-      for (int wi = 0; wi < W; wi++) {
-        const uint32_t lo = cur.w[wi];
-        const uint32_t hi = (wi + 1 < W) ? cur.w[wi + 1 < W ? wi + 1 : wi] : 0u;
-        const int s_end = first_sub[wi + 1];
-        for (; s < s_end; s++) {
-          const SubDesc sd = sub[s];
+    for (int wi = 0; wi < W; wi++) {
+      const uint32_t lo = it.w[wi];
+      const uint32_t hi = (wi + 1 < W) ? it.w[wi + 1 < W ? wi + 1 : wi] : 0u;
+      const int s_end = first_sub[wi + 1];
+      if (s < first_sub[wi]) s = first_sub[wi];
+      for (; s < s_end; s++) {
+        if (s < s_from) continue;
+        const SubDesc sd = sub[s];
+        if (!ea || alive) {
           const uint32_t c =
               __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
           chain(s, lut[sd.lut_off + c], acc, dism);
+          if (ea && (s & 3) == 3) alive = cx.survives(acc);
         }
       }
-      cx.admit(acc, row, valid);
+    }
+    return alive;
+  };
+
+  if (EA == EA_NONE) {
+    Item pf[PREFETCH];
+#pragma unroll
+    for (int i = 0; i < PREFETCH; i++)
+      if (i < n_steps) pf[i].load(p.codes, tile0 + (int64_t)i * nwaves, lane);
+    for (int st = 0; st < n_steps; st++) {
+      const Item cur = pf[0];
+#pragma unroll
+      for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
+      if (st + PREFETCH < n_steps)
+        pf[PREFETCH - 1].load(p.codes, tile0 + (int64_t)(st + PREFETCH) * nwaves, lane);
+      cx.refresh(st);
+      const int row = (int)(tile0 + (int64_t)st * nwaves) * TILE_ROWS + lane;
+      float acc[QB], dism[QB];
+#pragma unroll
+      for (int q = 0; q < QB; q++) { acc[q] = 0.0f; dism[q] = 0.0f; }
+      tail_inplace(cur, 0, acc, dism, true, false);
+      cx.admit(acc, row, row < r1);
+    }
+  } else {
+    // Early abandon over the bucketed row order (see scan_bytes_kernel)
+    const int per_wave = ((r1 - r0 + nwaves * TILE_ROWS - 1) / (nwaves * TILE_ROWS)) * TILE_ROWS;
+    const int w0 = r0 + wave * per_wave;
+    const int w1 = (w0 + per_wave < r1) ? w0 + per_wave : r1;
+    const int *__restrict__ bstart = p.bucket_start;
+    const SubDesc s1 = sub[1], s2 = sub[2], s3 = sub[3];
+    if (w0 < w1) {
+      int lo = 0, hi = p.n_buckets;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bstart[mid] <= w0) lo = mid; else hi = mid;
+      }
+      int b = lo, pos = w0, stepno = 0;
+      while (pos < w1) {
+        int be = bstart[b + 1];
+        if (be > w1) be = w1;
+        if (be > pos) {
+          const LT l0v = lut[b];  // subspace 0's table starts the packed LUT
+          float l0[QB];
+#pragma unroll
+          for (int q = 0; q < QB; q++)
+            l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+          if (cx.survives(l0)) {
+            const int base0 = pos & ~(TILE_ROWS - 1);
+            const int nst = (be - base0 + TILE_ROWS - 1) / TILE_ROWS;
+            Item pf[PREFETCH];
+#pragma unroll
+            for (int i = 0; i < PREFETCH; i++)
+              if (i < nst) pf[i].load(p.codes, base0 / TILE_ROWS + i, lane);
+            for (int t = 0; t < nst; t++) {
+              const Item cur = pf[0];
+#pragma unroll
+              for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
+              if (t + PREFETCH < nst) pf[PREFETCH - 1].load(p.codes, base0 / TILE_ROWS + t + PREFETCH, lane);
+              const int base = base0 + t * TILE_ROWS;
+              cx.refresh(stepno++);
+              const int row = base + lane;
+              const uint32_t w0w = cur.w[0];
+              const uint32_t w1w = W > 1 ? cur.w[W > 1 ? 1 : 0] : 0u;
+              float acc[QB], dism[QB];
+#pragma unroll
+              for (int q = 0; q < QB; q++) { acc[q] = 0.0f; dism[q] = l0[q]; }  // dism = l0
+              // A: dism += l1 (field 1 lies inside dword 0)
+              chain(1, lut[s1.lut_off + ((w0w >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
+              bool live = (row >= pos) && (row < be) && cx.survives(dism);
+              if (live) {
+                // A2: fields 2 and 3 (dwords 0..1) complete the first group
+                const uint32_t c2 = (s2.word == 0 ? __builtin_amdgcn_alignbit(w1w, w0w, (unsigned)s2.shift)
+                                                  : (w1w >> s2.shift)) & (unsigned)(s2.ncent - 1);
+                const uint32_t c3 = (s3.word == 0 ? __builtin_amdgcn_alignbit(w1w, w0w, (unsigned)s3.shift)
+                                                  : (w1w >> s3.shift)) & (unsigned)(s3.ncent - 1);
+                chain(2, lut[s2.lut_off + c2], acc, dism);
+                chain(3, lut[s3.lut_off + c3], acc, dism);
+                live = cx.survives(acc);
+              }
+              if (EA == EA_QUEUE) {
+                cx.push(live, row, acc);
+                while (cx.qcnt >= 64) drain(64);
+              } else {
+                live = tail_inplace(cur, 4, acc, dism, live, true);
+                cx.admit(acc, row, live);
+              }
+            }
+          }
+          pos = be;
+        }
+        b++;
+      }
     }
   }
   if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);

@@ -76,7 +76,7 @@ struct vaqhip_index {
   int device = 0, n_cu = 256;
   std::vector<int> bits;
   std::vector<vaq::SubDesc> sub;
-  DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes;
+  DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
   bool has_eig = false;
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
@@ -125,7 +125,9 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
     const int nqb_est = (nq + 1) / 2;
     ea = (stream_bytes > 256e6 && nqb_est <= INPLACE_MAX_BATCHES) ? vaq::EA_INPLACE : vaq::EA_QUEUE;
   }
-  int qb = ix->opt_qb > 0 ? ix->opt_qb : 2;
+  // default queries per pass: 2 for byte codes (one ds_read_b64 serves both), 1 for the
+  // bit-packed path (more whole buckets are skipped when only one query has to agree)
+  int qb = ix->opt_qb > 0 ? ix->opt_qb : (ix->layout == vaq::LAYOUT_BYTES ? 2 : 1);
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
   // the selection state are per workgroup, the survivor queues per wave; a CU
@@ -263,6 +265,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.W = ix->W;
     sp.sub = ix->d_sub.as<vaq::SubDesc>();
     sp.first_sub = ix->d_first_sub.as<int>();
+    sp.perm = ix->d_perm.as<uint32_t>();
+    sp.bucket_start = ix->d_bstart.as<int>();
+    sp.n_buckets = 1 << ix->bits[0];
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
     sp.nq = n;
@@ -427,7 +432,8 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
       (void)hipStreamDestroy(ix->stream);
     }
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->w_q,
+    for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
+                      &ix->d_bstart, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_labels,
                       &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id})
       b->release();
@@ -451,23 +457,36 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
   HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
   const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
+  const int K0 = 1 << ix->bits[0];
+  HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
+  HIP_TRY(ix->d_perm.ensure(std::max<size_t>((size_t)N, 1) * sizeof(uint32_t)));
+  std::vector<int> bstart((size_t)K0 + 1, (int)N);
   if (N == 0) {
     HIP_TRY(hipMemsetAsync(ix->d_codes.p, 0, (size_t)words * sizeof(uint32_t), st));
-  } else if (on_device) {
-    HIP_TRY(vaq::launch_pack_codes(codes, 0, N, padded, ix->M, ix->layout, ix->W, dsub,
-                                   ix->d_codes.as<uint32_t>(), st));
   } else {
-    const int64_t chunk = std::min<int64_t>(N, UPLOAD_CHUNK_ROWS);
-    HIP_TRY(ix->w_stage.ensure((size_t)chunk * ix->M * sizeof(uint16_t)));
-    for (int64_t r = 0; r < N; r += chunk) {
-      const int64_t e = std::min(N, r + chunk);
-      HIP_TRY(hipMemcpyAsync(ix->w_stage.p, codes + r * ix->M, (size_t)(e - r) * ix->M * sizeof(uint16_t),
-                             hipMemcpyHostToDevice, st));
-      HIP_TRY(vaq::launch_pack_codes(ix->w_stage.as<uint16_t>(), r, e, e == N ? padded : e, ix->M,
-                                     ix->layout, ix->W, dsub, ix->d_codes.as<uint32_t>(), st));
-      HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused
+    // all rows must be resident to sort them: stage a host matrix on the device first
+    DevBuf staged;
+    const uint16_t *d_u16 = codes;
+    if (!on_device) {
+      HIP_TRY(staged.ensure((size_t)N * ix->M * sizeof(uint16_t)));
+      for (int64_t r = 0; r < N; r += UPLOAD_CHUNK_ROWS) {
+        const int64_t e = std::min(N, r + UPLOAD_CHUNK_ROWS);
+        HIP_TRY(hipMemcpyAsync(staged.as<uint16_t>() + r * ix->M, codes + r * ix->M,
+                               (size_t)(e - r) * ix->M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+      }
+      d_u16 = staged.as<uint16_t>();
     }
+    HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], ix->d_perm.as<uint32_t>(),
+                                    ix->d_bstart.as<int>(), st));
+    HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    bstart[K0] = (int)N;
+    for (int b = K0 - 1; b >= 0; b--)
+      if (bstart[b] < 0) bstart[b] = bstart[b + 1];  // codes that do not occur: empty bucket
+    HIP_TRY(vaq::launch_pack_codes(d_u16, 0, N, padded, ix->M, ix->layout, ix->W, dsub,
+                                   ix->d_perm.as<uint32_t>(), ix->d_codes.as<uint32_t>(), st));
+    HIP_TRY(hipStreamSynchronize(st));  // `staged` is freed on return
   }
+  HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
   ix->N = N;
   ix->id_base = id_base;
   return VAQHIP_OK;
@@ -748,6 +767,11 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     ix->opt_slices = (int)value;
   } else if (k == "timing") {
     ix->opt_timing = value != 0;
+    if (ix->opt_timing) {  // create the event ring now, not inside the first timed search
+      DeviceGuard g(ix->device);
+      int rc = ensure_events(ix);
+      if (rc) return rc;
+    }
   } else if (k == "early_abandon") {
     if (value < 0 || value > 3) return fail(VAQHIP_EINVAL, "early_abandon must be 0..3");
     ix->opt_ea = (int)value;
