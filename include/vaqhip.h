@@ -83,7 +83,9 @@ void vaqhip_index_destroy(vaqhip_index *ix);
  * Replaces the `mCodebook` member filled by VAQ::encode (VAQ.cpp:663-726) or
  * loadCodebook (utils/IO.hpp:551-571).  Calling it again replaces the codes.
  * id_base: global row index of local row 0 (shard offset); labels
- * returned by search are id_base + local row and must stay < 2^31. */
+ * returned by search are id_base + local row and must stay < 2^31.
+ * Both forms sort the rows by their first code on the GPU (bucketed order,
+ * DESIGN.md section 3) and therefore synchronise; the _device form does so on `stream`. */
 int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor,
                                int64_t N, int64_t id_base);
 int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
