@@ -243,6 +243,17 @@ def main():
         "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
     }
 
+    # HBM-side traffic of the scan kernel comes from separate rocprofv3 --pmc passes of this
+    # same command (tools/profile_gpu.sh); the corrected per-launch figure is committed under
+    # profiles/ and attached here when it matches the workload and plan.
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
+        if tr and world == 1 and not args.rows and not args.nq and tm["queries_per_pass"] == 2:
+            roofline["traffic"] = tr["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
+    except (OSError, ValueError):
+        pass
+
     # --------------------------------------------------------------- recall --
     recall = None
     if not args.no_recall and real_codes and N <= 4_000_000 and rank == 0:
