@@ -75,6 +75,17 @@ int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
                         const float *const *centroids_rowmajor,
                         const float *eigvec_real_rowmajor, int device_id);
 
+/* Same with flags.  VAQHIP_SUM_SEQUENTIAL selects the row sum of the reference's other
+ * entry on this path, BitVecEngine::queryLUT (BitVecEngine.hpp:1222-1343): one scalar
+ * quantiser per PCA dimension (D == M, sub-vector length 1), LUT column stride 256, and
+ * dist = ((l_0 + l_1) + l_2) + ... summed column by column (:1296-1300) instead of in
+ * groups of four; M need not be a multiple of 4.  centroids[s] is then column s of the
+ * engine's centroidsMat (1 << bits[s] values). */
+#define VAQHIP_SUM_SEQUENTIAL 0x1u
+int vaqhip_index_create_ex(vaqhip_index **out, int D, int M, const int *bits,
+                           const float *const *centroids_rowmajor,
+                           const float *eigvec_real_rowmajor, int device_id, unsigned flags);
+
 void vaqhip_index_destroy(vaqhip_index *ix);
 
 /* mCodebook (CodebookType = RowMatrix<uint16_t>, utils/Types.hpp:31), N x M

@@ -223,5 +223,63 @@ private:
   bool codes_set_ = false;
 };
 
+// ---------------------------------------------------------------------------
+// BitVecEngine::queryLUT (BitVecEngine.hpp:1222-1343), the reference's other
+// entry on this path: one scalar quantiser per PCA dimension, columns summed
+// one by one.  The engine keeps its state private (centroidsMat, solutionX,
+// eigenVectors, nonZeroAllocCount: BitVecEngine.hpp:33-39); here it is public.
+// ---------------------------------------------------------------------------
+struct IdxDistPairFloat {  // utils/Types.hpp:41-57
+  int idx;
+  float dist;
+};
+
+class BitVecEngineHip {
+public:
+  std::vector<float> centroidsMat;  // column-major, `centroidRows` (256) rows x nonZeroAllocCount columns
+  int centroidRows = 256;
+  std::vector<int> solutionX;       // bits per dimension
+  RowMatrixF eigenVectors;          // real part, D x D, D = nonZeroAllocCount (empty = identity)
+  int mDevice = 0;
+
+  BitVecEngineHip() = default;
+  BitVecEngineHip(const BitVecEngineHip &) = delete;
+  BitVecEngineHip &operator=(const BitVecEngineHip &) = delete;
+  ~BitVecEngineHip() { vaqhip_index_destroy(h_); }
+  void invalidate() { vaqhip_index_destroy(h_); h_ = nullptr; }
+
+  // queries: any row-major float matrix with data()/rows()/cols() (the reference
+  // takes a column-major Eigen::MatrixXf: pass its transpose's storage or a RowMatrixF)
+  template <class Mat, class Codebook>
+  std::vector<std::vector<IdxDistPairFloat>> queryLUT(const Mat &queries, const int k, const Codebook &codebook) {
+    const int nd = (int)solutionX.size();
+    if (!h_) {
+      std::vector<std::vector<float>> cols(nd);
+      std::vector<const float *> cp(nd);
+      for (int d = 0; d < nd; d++) {
+        cols[d].assign(centroidsMat.begin() + (size_t)d * centroidRows,
+                       centroidsMat.begin() + (size_t)d * centroidRows + ((size_t)1 << solutionX[d]));
+        cp[d] = cols[d].data();
+      }
+      check(vaqhip_index_create_ex(&h_, nd, nd, solutionX.data(), cp.data(),
+                                   eigenVectors.rows() ? eigenVectors.data() : nullptr, mDevice,
+                                   VAQHIP_SUM_SEQUENTIAL));
+    }
+    check(vaqhip_index_set_codes_u16(h_, codebook.data(), (int64_t)codebook.rows(), 0));
+    const int nq = (int)queries.rows();
+    std::vector<int> lab((size_t)nq * k);
+    std::vector<float> dis((size_t)nq * k);
+    check(vaqhip_search(h_, queries.data(), nq, k, lab.data(), dis.data()));
+    std::vector<std::vector<IdxDistPairFloat>> answers(nq);
+    for (int q = 0; q < nq; q++)
+      for (int i = 0; i < k && lab[(size_t)q * k + i] >= 0; i++)
+        answers[q].push_back({lab[(size_t)q * k + i], dis[(size_t)q * k + i]});
+    return answers;
+  }
+
+private:
+  vaqhip_index *h_ = nullptr;
+};
+
 } // namespace vaqhip
 #endif

@@ -347,3 +347,46 @@ def test_search_then_refine_pipeline(vaqlib, oracle):
     o_l, o_d = oracle.search(Q, cents, v.mCodebook, 200, eig=eig)
     o_rl, o_rd = oracle.refine(Q, X, o_l, 100)
     assert_topk_matches(fin.labels.reshape(16, 100), fin.distances.reshape(16, 100), o_rl, o_rd)
+
+
+@pytest.mark.parametrize("ndim,seed", [(10, 1), (3, 2), (37, 3), (64, 4)])
+def test_query_lut_sequential(vaqlib, oracle, ndim, seed):
+    """The reference's other entry on this path, BitVecEngine::queryLUT
+    (BitVecEngine.hpp:1222-1343): one scalar quantiser per PCA dimension, columns
+    summed one by one, any number of dimensions (not a multiple of 4)."""
+    import vaq_amd
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(1, 9, ndim).tolist() if ndim * 8 > 256 else rng.integers(1, 9, ndim).tolist()
+    while sum(bits) > 256:
+        bits[int(np.argmax(bits))] -= 1
+    N, nq, k = 20000, 6, 50
+    cent = np.zeros((256, ndim), np.float32)
+    for d, b in enumerate(bits):
+        cent[: 1 << b, d] = np.sort(rng.normal(size=1 << b) * 20).astype(np.float32)
+    codes = np.stack([rng.integers(0, 1 << b, N) for b in bits], 1).astype(np.uint16)
+    codes[N // 2:N // 2 + 500] = codes[:500]          # duplicates: exact ties
+    q, _ = np.linalg.qr(rng.normal(size=(ndim, ndim)))
+    eig = q.astype(np.float32)
+    X = (rng.normal(size=(nq, ndim)) * 20).astype(np.float32)
+    v = vaq_amd.VaqHip(sequential_sum=True)
+    v.mBitsAlloc = bits
+    v.mCentroidsPerSubs = [np.ascontiguousarray(cent[: 1 << b, d:d + 1]) for d, b in enumerate(bits)]
+    v.mEigenVectors = eig
+    v.mCodebook = codes
+    Xp = oracle.project(X, eig)
+    o_lab = np.empty((nq, k), np.int32)
+    o_dis = np.empty((nq, k), np.float32)
+    ad = np.empty((nq, N), np.float32)
+    for i in range(nq):
+        o_lab[i], o_dis[i] = oracle.query_lut_1d(Xp[i], bits, cent, codes, k)
+        lut = [np.float32((Xp[i, d] - cent[: 1 << bits[d], d]) ** 2) for d in range(ndim)]
+        acc = lut[0][codes[:, 0]].astype(np.float32)
+        for d in range(1, ndim):
+            acc = (acc + lut[d][codes[:, d]]).astype(np.float32)
+        ad[i] = acc
+    for qb, ea in [(1, 3), (2, 1), (4, 2), (1, 0), (2, 2)]:
+        v.set_option("queries_per_pass", qb)
+        v.set_option("early_abandon", ea)
+        a = v.search(X, k)
+        assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
+                            what=f"queryLUT ndim={ndim} qb={qb} ea={ea}")

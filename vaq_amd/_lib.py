@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libvaqhip.so")
 
 # every symbol include/vaqhip.h declares
 SYMBOLS = [
-    "vaqhip_index_create", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
+    "vaqhip_index_create", "vaqhip_index_create_ex", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
     "vaqhip_index_set_codes_u16_device", "vaqhip_search", "vaqhip_search_projected",
     "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
     "vaqhip_encode", "vaqhip_encode_device", "vaqhip_refine", "vaqhip_refine_device",
@@ -78,6 +78,8 @@ def load():
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.vaqhip_index_create.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(i32),
                                       C.POINTER(C.POINTER(C.c_float)), vp, i32]
+    L.vaqhip_index_create_ex.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(i32),
+                                         C.POINTER(C.POINTER(C.c_float)), vp, i32, C.c_uint]
     L.vaqhip_index_destroy.argtypes = [vp]
     L.vaqhip_index_destroy.restype = None
     L.vaqhip_index_set_codes_u16.argtypes = [vp, vp, i64, i64]

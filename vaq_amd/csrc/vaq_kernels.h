@@ -64,6 +64,7 @@ struct ScanParams {
   int64_t slice_stride;   // rows between slice starts (== slice_rows for a full scan,
                           // larger for the sampling pre-pass)
   int share_thr;          // 1: exchange thresholds between workgroups through g_thr
+  int seq;                // 1: sequential row sum (BitVecEngine::queryLUT) instead of groups of 4
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };

@@ -1010,14 +1010,23 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
   const int *__restrict__ first_sub = p.first_sub;
   const uint32_t *__restrict__ codes = p.codes;
 
-  // one more subspace of the reference's chain: dism = l0; dism += l1..l3; dist += dism
+  // one more subspace of the reference's chain.
+  //   grouped (VAQ::searchHeap, VAQ.cpp:1737-1748): dism = l0; dism += l1..l3; dist += dism
+  //   sequential (BitVecEngine::queryLUT, BitVecEngine.hpp:1296-1300): dist += l_s
+  //     (dism mirrors dist so the survivor tests read the same variable in both modes)
+  const bool seq = p.seq != 0;
   auto chain = [&](const int s, const LT l, float (&acc)[QB], float (&dism)[QB]) {
     const int ph = s & 3;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       const float x = lv_get<QB>(l, q);
-      dism[q] = (ph == 0) ? x : dism[q] + x;
-      if (ph == 3) acc[q] = (s == 3) ? dism[q] : acc[q] + dism[q];
+      if (seq) {
+        acc[q] = (s == 0) ? x : acc[q] + x;
+        dism[q] = acc[q];
+      } else {
+        dism[q] = (ph == 0) ? x : dism[q] + x;
+        if (ph == 3) acc[q] = (s == 3) ? dism[q] : acc[q] + dism[q];
+      }
     }
   };
 
@@ -1050,7 +1059,7 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
         const uint32_t c =
             __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
         chain(s, lut[sd.lut_off + c], acc, dism);
-        if ((s & 3) == 3) alive = cx.survives(acc);
+        if (seq || (s & 3) == 3) alive = cx.survives(acc);
       }
     }
     cx.admit(acc, rid, alive);
@@ -1073,7 +1082,7 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
           const uint32_t c =
               __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
           chain(s, lut[sd.lut_off + c], acc, dism);
-          if (ea && (s & 3) == 3) alive = cx.survives(acc);
+          if (ea && (seq || (s & 3) == 3)) alive = cx.survives(acc);
         }
       }
     }
@@ -1105,7 +1114,8 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
     const int w0 = r0 + wave * per_wave;
     const int w1 = (w0 + per_wave < r1) ? w0 + per_wave : r1;
     const int *__restrict__ bstart = p.bucket_start;
-    const SubDesc s1 = sub[1], s2 = sub[2], s3 = sub[3];
+    // subspaces 1..3 complete the first group (sequential mode may have fewer than 4)
+    const SubDesc s1 = sub[M > 1 ? 1 : 0], s2 = sub[M > 2 ? 2 : 0], s3 = sub[M > 3 ? 3 : 0];
     if (w0 < w1) {
       int lo = 0, hi = p.n_buckets;
       while (hi - lo > 1) {
@@ -1141,19 +1151,20 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
               const uint32_t w1w = W > 1 ? cur.w[W > 1 ? 1 : 0] : 0u;
               float acc[QB], dism[QB];
 #pragma unroll
-              for (int q = 0; q < QB; q++) { acc[q] = 0.0f; dism[q] = l0[q]; }  // dism = l0
+              for (int q = 0; q < QB; q++) { acc[q] = l0[q]; dism[q] = l0[q]; }  // dism = l0 / dist = l0
               // A: dism += l1 (field 1 lies inside dword 0)
-              chain(1, lut[s1.lut_off + ((w0w >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
+              if (M > 1)
+                chain(1, lut[s1.lut_off + ((w0w >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
               bool live = (row >= pos) && (row < be) && cx.survives(dism);
-              if (live) {
+              if (live && M > 2) {
                 // A2: fields 2 and 3 (dwords 0..1) complete the first group
                 const uint32_t c2 = (s2.word == 0 ? __builtin_amdgcn_alignbit(w1w, w0w, (unsigned)s2.shift)
                                                   : (w1w >> s2.shift)) & (unsigned)(s2.ncent - 1);
                 const uint32_t c3 = (s3.word == 0 ? __builtin_amdgcn_alignbit(w1w, w0w, (unsigned)s3.shift)
                                                   : (w1w >> s3.shift)) & (unsigned)(s3.ncent - 1);
                 chain(2, lut[s2.lut_off + c2], acc, dism);
-                chain(3, lut[s3.lut_off + c3], acc, dism);
-                live = cx.survives(acc);
+                if (M > 3) chain(3, lut[s3.lut_off + c3], acc, dism);
+                live = cx.survives(seq ? acc : (M > 3 ? acc : dism));
               }
               if (EA == EA_QUEUE) {
                 cx.push(live, row, acc);

@@ -78,6 +78,7 @@ struct vaqhip_index {
   std::vector<vaq::SubDesc> sub;
   DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
   bool has_eig = false;
+  int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
@@ -276,6 +277,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.ccap = pl.ccap;
     sp.qcap = pl.qcap;
     sp.ea = pl.ea;
+    sp.seq = ix->seq;
     sp.nwaves = pl.nwaves;
     sp.g_thr = ix->w_thr.as<unsigned>();
     sp.qb = pl.qb;
@@ -337,11 +339,19 @@ int vaqhip_device_count(void) {
 
 int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
                         const float *const *centroids, const float *eig, int device_id) {
+  return vaqhip_index_create_ex(out, D, M, bits, centroids, eig, device_id, 0u);
+}
+
+int vaqhip_index_create_ex(vaqhip_index **out, int D, int M, const int *bits,
+                           const float *const *centroids, const float *eig, int device_id,
+                           unsigned flags) {
   if (!out) return fail(VAQHIP_EINVAL, "out is null");
+  const bool seq = (flags & VAQHIP_SUM_SEQUENTIAL) != 0;
+  if (flags & ~(unsigned)VAQHIP_SUM_SEQUENTIAL) return fail(VAQHIP_EINVAL, "unknown flags 0x%x", flags);
   *out = nullptr;
   if (D <= 0 || M <= 0 || !bits || !centroids) return fail(VAQHIP_EINVAL, "bad D/M/bits/centroids");
   if (M > VAQHIP_MAX_SUBSPACES) return fail(VAQHIP_EUNSUPPORTED, "M=%d > %d", M, VAQHIP_MAX_SUBSPACES);
-  if (M % 4 != 0)
+  if (M % 4 != 0 && !seq)
     return fail(VAQHIP_EINVAL, "M=%d: the reference scan reads 4 codes per step (VAQ.cpp:1741-1746)", M);
   if (D % M != 0) return fail(VAQHIP_EINVAL, "D=%d is not a multiple of M=%d", D, M);
   int ndev = 0;
@@ -386,7 +396,8 @@ int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
   ix->total_bits = bit_off;
   ix->lut_floats = lut_off;
   ix->W = (bit_off + 31) / 32;
-  ix->layout = (all8 && (M == 8 || M == 16 || M == 32)) ? vaq::LAYOUT_BYTES : vaq::LAYOUT_BITS;
+  ix->seq = seq ? 1 : 0;
+  ix->layout = (!seq && all8 && (M == 8 || M == 16 || M == 32)) ? vaq::LAYOUT_BYTES : vaq::LAYOUT_BITS;
   if (ix->layout == vaq::LAYOUT_BITS && ix->W > 8)
     return fail(VAQHIP_EUNSUPPORTED, "%d code bits per row; this build packs at most 256", bit_off);
   std::vector<int> first_sub(ix->W + 1, M);

@@ -55,8 +55,12 @@ class VaqHip:
         ans = vaq.search(XTest, 100)           # LabelDistVec
     """
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, sequential_sum: bool = False):
+        """sequential_sum=True: BitVecEngine::queryLUT's arithmetic (one scalar
+        quantiser per dimension, columns summed one by one; M need not be a
+        multiple of 4) instead of VAQ::searchHeap's groups of four."""
         self.device = device
+        self.sequential_sum = sequential_sum
         # VAQ.hpp:51-55
         self.mBitBudget = 0
         self.mSubspaceNum = 0
@@ -148,7 +152,7 @@ class VaqHip:
             if eig.shape != (D, D):
                 raise _lib.VaqHipError(-1, f"mEigenVectors {eig.shape} is not {D}x{D}")
         sig = (tuple(self.mBitsAlloc), tuple(id(c) for c in self.mCentroidsPerSubs),
-               id(self.mEigenVectors), self.device)
+               id(self.mEigenVectors), self.device, self.sequential_sum)
         if self._h and sig == self._sig:
             return
         self.close()
@@ -157,8 +161,9 @@ class VaqHip:
         for i, c in enumerate(cents):
             arr[i] = c.ctypes.data_as(C.POINTER(C.c_float))
         h = C.c_void_p()
-        _lib.check(L.vaqhip_index_create(C.byref(h), D, M, bits, arr,
-                                         _ptr(eig) if eig is not None else None, self.device))
+        _lib.check(L.vaqhip_index_create_ex(C.byref(h), D, M, bits, arr,
+                                            _ptr(eig) if eig is not None else None, self.device,
+                                            1 if self.sequential_sum else 0))
         self._h = h
         self._sig = sig
         self._codes_sig = None
