@@ -539,6 +539,14 @@ __device__ __forceinline__ bool sel_fold(const SelView &v, int k, int kp, int la
 __device__ __forceinline__ int xcd_virtual_id(int b, int G) { return (b & 7) * (G >> 3) + (b >> 3); }
 
 constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
+// A CU admits waves by SGPR allocation too: above 80 SGPRs only 6-7 waves fit a
+// SIMD instead of 8 (MI355X_MICROARCH.md, "Residency").  The scan kernels are
+// latency-bound, so cap them and let the compiler keep the overflow in VGPR lanes.
+#ifndef VAQ_SCAN_SGPR_CAP
+#define VAQ_SCAN_SGPR_CAP 80
+#endif
+// (not the in-place form: it is HBM-bound with waves to spare and only pays for the spills)
+#define VAQ_SCAN_SGPRS __attribute__((amdgpu_num_sgpr(VAQ_SCAN_SGPR_CAP)))
 #ifndef VAQ_PREFETCH
 #define VAQ_PREFETCH 2
 #endif
@@ -777,7 +785,7 @@ template <int M> struct BytesItem {
 // Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
 template <int M, int QB, int EA>
-__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_kernel(ScanParams p) {
+__device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
   constexpr int WPR = Item::WPR;
@@ -982,7 +990,7 @@ template <int W> struct BitsItem {
 };
 
 template <int W, int QB, int EA>
-__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams p) {
+__device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1185,6 +1193,24 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_kernel(ScanParams 
   cx.write_out(p, slice, qbatch);
 }
 
+// __global__ entry points: the SGPR-capped one for EA_NONE / EA_QUEUE, a plain one for EA_INPLACE
+template <int M, int QB, int EA>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_kernel(ScanParams p) {
+  scan_bytes_body<M, QB, EA>(p);
+}
+template <int M, int QB>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_inplace_kernel(ScanParams p) {
+  scan_bytes_body<M, QB, EA_INPLACE>(p);
+}
+template <int W, int QB, int EA>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bits_kernel(ScanParams p) {
+  scan_bits_body<W, QB, EA>(p);
+}
+template <int W, int QB>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_inplace_kernel(ScanParams p) {
+  scan_bits_body<W, QB, EA_INPLACE>(p);
+}
+
 // ---- launch geometry shared with the host --------------------------------
 static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
 
@@ -1220,9 +1246,9 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
 
 #define VAQ_DISPATCH_EA(KERNEL, A, Q)                                                     \
   switch (p.ea) {                                                                         \
-  case EA_NONE: return launch_scan_kernel(KERNEL<A, Q, EA_NONE>, p, lds, grid, st);       \
-  case EA_QUEUE: return launch_scan_kernel(KERNEL<A, Q, EA_QUEUE>, p, lds, grid, st);     \
-  case EA_INPLACE: return launch_scan_kernel(KERNEL<A, Q, EA_INPLACE>, p, lds, grid, st); \
+  case EA_NONE: return launch_scan_kernel(KERNEL##_kernel<A, Q, EA_NONE>, p, lds, grid, st);   \
+  case EA_QUEUE: return launch_scan_kernel(KERNEL##_kernel<A, Q, EA_QUEUE>, p, lds, grid, st); \
+  case EA_INPLACE: return launch_scan_kernel(KERNEL##_inplace_kernel<A, Q>, p, lds, grid, st); \
   default: return hipErrorInvalidValue;                                                   \
   }
 #define VAQ_DISPATCH_QB(KERNEL, A)                                                        \
@@ -1242,21 +1268,21 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.k, p.ea, p.nwaves);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
-    case 8:  VAQ_DISPATCH_QB(scan_bytes_kernel, 8)
-    case 16: VAQ_DISPATCH_QB(scan_bytes_kernel, 16)
-    case 32: VAQ_DISPATCH_QB(scan_bytes_kernel, 32)
+    case 8:  VAQ_DISPATCH_QB(scan_bytes, 8)
+    case 16: VAQ_DISPATCH_QB(scan_bytes, 16)
+    case 32: VAQ_DISPATCH_QB(scan_bytes, 32)
     default: return hipErrorInvalidValue;
     }
   }
   switch (p.W) {
-  case 1: VAQ_DISPATCH_QB(scan_bits_kernel, 1)
-  case 2: VAQ_DISPATCH_QB(scan_bits_kernel, 2)
-  case 3: VAQ_DISPATCH_QB(scan_bits_kernel, 3)
-  case 4: VAQ_DISPATCH_QB(scan_bits_kernel, 4)
-  case 5: VAQ_DISPATCH_QB(scan_bits_kernel, 5)
-  case 6: VAQ_DISPATCH_QB(scan_bits_kernel, 6)
-  case 7: VAQ_DISPATCH_QB(scan_bits_kernel, 7)
-  case 8: VAQ_DISPATCH_QB(scan_bits_kernel, 8)
+  case 1: VAQ_DISPATCH_QB(scan_bits, 1)
+  case 2: VAQ_DISPATCH_QB(scan_bits, 2)
+  case 3: VAQ_DISPATCH_QB(scan_bits, 3)
+  case 4: VAQ_DISPATCH_QB(scan_bits, 4)
+  case 5: VAQ_DISPATCH_QB(scan_bits, 5)
+  case 6: VAQ_DISPATCH_QB(scan_bits, 6)
+  case 7: VAQ_DISPATCH_QB(scan_bits, 7)
+  case 8: VAQ_DISPATCH_QB(scan_bits, 8)
   default: return hipErrorInvalidValue;
   }
 }
