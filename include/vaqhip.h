@@ -179,6 +179,9 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *   "timing"            1: record hipEvents (on the search's own stream) around
  *                       each kernel of every following search, up to 256
  *                       searches between two vaqhip_last_timing reads
+ *   "hot_buckets"       0..32 (default 32): buckets (rows sharing their first code) each
+ *                       workgroup scans best-first, closest first term first, before
+ *                       the rest of its slice; 0 = natural order only
  *   "waves_per_workgroup" 0 = auto (most wavefronts per CU), else 4, 8 or 16
  *   "seed_thresholds"   1 (default): when a query's rows are split over several
  *                       workgroups, a pre-pass over 1/64 of the rows seeds their

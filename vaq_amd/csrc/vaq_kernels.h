@@ -47,6 +47,7 @@ struct ScanParams {
   const uint32_t *perm;   // [n_rows] sorted row -> original row (labels), or nullptr = identity
   const int *bucket_start;// [n_buckets + 1] first sorted row of each subspace-0 code
   int n_buckets;          // 1 << bits[0]
+  int n_hot;              // buckets a workgroup scans best-first before the rest (0 = off, <= 32)
   const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
   const float *lut;       // [nq][lut_floats]
   int lut_floats;

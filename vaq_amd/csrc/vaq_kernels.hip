@@ -554,6 +554,11 @@ constexpr int PREFETCH = VAQ_PREFETCH;  // items loaded ahead of the one being p
 constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
 constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
 constexpr int THR_GLOBAL_EVERY = 64;
+constexpr int HOT_MAX = 32;            // buckets scanned best-first
+constexpr int HOT_MAX_BUCKETS = 4096;  // best-first needs 1 << bits[0] <= this (rank scratch, mask)
+constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
+constexpr int HOT_SEG_STEPS = 16;      // wave steps per best-first work unit
+constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
 
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
@@ -572,6 +577,82 @@ template <int QB> struct ScanCtx {
   bool multi_slice;
   unsigned *g_thr;
   const uint32_t *perm;
+  // best-first phase: the n_hot buckets whose first term is smallest for this
+  // query batch are scanned before the rest (so the thresholds are near-final
+  // when the remaining buckets are tested for skipping)
+  int *hot_bucket;     // [HOT_MAX] bucket ids in ascending-key order, -1 = none
+  int *hot_pre;        // [HOT_MAX + 1] prefix of segment counts
+  unsigned *hot_mask;  // [HOT_MASK_WORDS] bit b set = bucket b is handled by the hot phase
+  unsigned *hot_ticket;
+  int n_hot;
+
+  // Rank the buckets of the slice [r0, r1) by key = min over the batch's queries of
+  // the first LUT term and keep the n_hot best.  Uses the (not yet staged) LUT
+  // region as scratch: one packed word (key's high bits | bucket) per bucket.
+  __device__ __forceinline__ void pick_hot(unsigned char *smem, const ScanParams &p, int r0, int r1,
+                                           int seg_rows, int wstep, int tid, int nthreads) {
+    const int K0 = p.n_buckets;
+    int K0p = 2;
+    while (K0p < K0) K0p <<= 1;
+    const unsigned idx_mask = (unsigned)K0p - 1u;
+    unsigned *tmp = reinterpret_cast<unsigned *>(smem);
+    const int *__restrict__ bstart = p.bucket_start;
+    for (int b = tid; b < K0p; b += nthreads) {
+      unsigned key = 0xffffffffu;
+      if (b < K0) {
+        const int s0 = bstart[b] > r0 ? bstart[b] : r0;
+        const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        if (e0 > s0) {
+          float m = p.lut[(size_t)qi[0] * p.lut_floats + b];
+#pragma unroll
+          for (int q = 1; q < QB; q++) {
+            const float x = p.lut[(size_t)qi[q] * p.lut_floats + b];
+            m = x < m ? x : m;
+          }
+          key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
+          if (m != m) key = 0xffffffffu;
+        }
+      }
+      tmp[b] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= K0p; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < (K0p >> 1); t += nthreads) {
+          const int i = 2 * t - (t & (stride - 1));
+          const int j = i + stride;
+          const unsigned a = tmp[i], c = tmp[j];
+          if ((a > c) == ((i & size) == 0)) { tmp[i] = c; tmp[j] = a; }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < HOT_MAX; i += nthreads) {
+      const unsigned k = (i < K0p) ? tmp[i] : 0xffffffffu;
+      hot_bucket[i] = (i < p.n_hot && k != 0xffffffffu) ? (int)(k & idx_mask) : -1;
+    }
+    for (int w = tid; w < HOT_MASK_WORDS; w += nthreads) hot_mask[w] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+      int acc = 0;
+      for (int i = 0; i < HOT_MAX; i++) {
+        hot_pre[i] = acc;
+        const int b = hot_bucket[i];
+        if (b >= 0) {
+          const int s0 = bstart[b] > r0 ? bstart[b] : r0;
+          const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+          acc += (e0 - (s0 & ~(wstep - 1)) + seg_rows - 1) / seg_rows;
+          hot_mask[b >> 5] |= 1u << (b & 31);
+        }
+      }
+      hot_pre[HOT_MAX] = acc;
+      *hot_ticket = 0u;
+    }
+    __syncthreads();
+  }
+
+  __device__ __forceinline__ bool is_hot(int b) const {
+    return n_hot > 0 && ((hot_mask[b >> 5] >> (b & 31)) & 1u);
+  }
 
   __device__ __forceinline__ void setup(unsigned char *smem, const ScanParams &p, int lut_entries,
                                         int qbatch, int tid, int nthreads) {
@@ -614,10 +695,20 @@ template <int QB> struct ScanCtx {
       }
     }
     off += QB * sb;
+    n_hot = p.n_hot;
+    hot_bucket = reinterpret_cast<int *>(smem + off);
+    hot_pre = hot_bucket + HOT_MAX;
+    hot_mask = reinterpret_cast<unsigned *>(hot_pre + HOT_MAX + 1);
+    hot_ticket = hot_mask + HOT_MASK_WORDS;
+    off += HOT_BYTES;
     const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
     unsigned char *qb = smem + off + (size_t)wave * q_bytes;
     q_id = reinterpret_cast<int *>(qb);
     q_p = reinterpret_cast<float *>(qb + (size_t)p.qcap * 4);
+  }
+
+  // copy the batch's LUTs into LDS, interleaved per entry (after pick_hot, which borrows the region)
+  __device__ __forceinline__ void stage_lut(const ScanParams &p, int lut_entries, int tid, int nthreads) {
     for (int e = tid; e < lut_entries; e += nthreads) {
       LT val;
 #pragma unroll
@@ -798,18 +889,22 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const int slice = v / nqb;
   const int qbatch = v - slice * nqb;
 
-  ScanCtx<QB> cx;
-  cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
-  const LT *lut = cx.lut;
-  const int lane = cx.lane, wave = cx.wave;
-  __syncthreads();
-
   // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the largest
   // workgroup step and the code buffer is padded to a multiple of it, so every
   // load is in bounds; rows >= n_rows are masked out.
   const int r0 = (int)((int64_t)slice * p.slice_stride);
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
+
+  ScanCtx<QB> cx;
+  cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
+  if (EA != EA_NONE && cx.n_hot > 0)
+    cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
+  cx.stage_lut(p, M * 256, tid, nthreads);
+  const LT *lut = cx.lut;
+  const int lane = cx.lane, wave = cx.wave;
+  __syncthreads();
+
   const int step_items = nthreads;  // items per workgroup step
   const int64_t item0 = r0 / Item::ROWS + wave * 64 + lane;
   const int step_rows = step_items * Item::ROWS;
@@ -895,17 +990,52 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     const int w0 = r0 + wave * per_wave;
     const int w1 = (w0 + per_wave < r1) ? w0 + per_wave : r1;
     const int *__restrict__ bstart = p.bucket_start;
+    constexpr int SEG_ROWS = HOT_SEG_STEPS * WSTEP;
+    // work units (bucket b, rows [pos, be)): first the best-first segments, pulled by
+    // ticket so that the waves share them, then this wave's own part of the slice in
+    // natural order (minus the buckets already done)
+    bool hot_phase = cx.n_hot > 0;
+    const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
+    int wb = 0, wpos = w0, stepno = 0;
     if (w0 < w1) {
       int lo = 0, hi = p.n_buckets;  // largest b with bstart[b] <= w0
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (bstart[mid] <= w0) lo = mid; else hi = mid;
       }
-      int b = lo, pos = w0, stepno = 0;
-      while (pos < w1) {
-        int be = bstart[b + 1];
+      wb = lo;
+    }
+    for (;;) {
+      int b, pos, be;
+      if (hot_phase) {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= hot_total) { hot_phase = false; continue; }
+        int i = 0;
+        while (cx.hot_pre[i + 1] <= t) i++;
+        b = cx.hot_bucket[i];
+        const int bs = bstart[b] > r0 ? bstart[b] : r0;
+        const int bend = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        const int al = bs & ~(WSTEP - 1);
+        const int j = t - cx.hot_pre[i];
+        pos = al + j * SEG_ROWS;
+        if (pos < bs) pos = bs;
+        be = al + (j + 1) * SEG_ROWS;
+        if (be > bend) be = bend;
+      } else {
+        if (wpos >= w1) break;
+        be = bstart[wb + 1];
         if (be > w1) be = w1;
-        if (be > pos) {
+        if (be <= wpos) { wb++; continue; }
+        b = wb;
+        pos = wpos;
+        wpos = be;
+        wb++;
+        if (cx.is_hot(b)) continue;
+      }
+      {
+        {
           // the bucket's first term, dism = l0, is wave-uniform
           const LT l0v = lut[b];
           float l0[QB];
@@ -962,9 +1092,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 while (cx.qcnt >= 64) drain(64);
             }
           }
-          pos = be;
         }
-        b++;
       }
     }
   }
@@ -1002,15 +1130,19 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   const int slice = v / nqb;
   const int qbatch = v - slice * nqb;
 
+  const int r0 = (int)((int64_t)slice * p.slice_stride);
+  const int64_t r1l = (int64_t)r0 + p.slice_rows;
+  const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
+
   ScanCtx<QB> cx;
   cx.setup(smem, p, p.lut_floats, qbatch, tid, nthreads);
+  if (EA != EA_NONE && cx.n_hot > 0)
+    cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
+  cx.stage_lut(p, p.lut_floats, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
   __syncthreads();
 
-  const int r0 = (int)((int64_t)slice * p.slice_stride);
-  const int64_t r1l = (int64_t)r0 + p.slice_rows;
-  const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
   const int64_t tile0 = r0 / TILE_ROWS + wave;
   const int n_steps = (r1 > r0) ? (r1 - r0 + nthreads - 1) / nthreads : 0;
   const int M = p.M;
@@ -1124,17 +1256,50 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
     const int *__restrict__ bstart = p.bucket_start;
     // subspaces 1..3 complete the first group (sequential mode may have fewer than 4)
     const SubDesc s1 = sub[M > 1 ? 1 : 0], s2 = sub[M > 2 ? 2 : 0], s3 = sub[M > 3 ? 3 : 0];
+    constexpr int WSTEP = TILE_ROWS;
+    constexpr int SEG_ROWS = HOT_SEG_STEPS * WSTEP;
+    bool hot_phase = cx.n_hot > 0;
+    const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
+    int wb = 0, wpos = w0, stepno = 0;
     if (w0 < w1) {
       int lo = 0, hi = p.n_buckets;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (bstart[mid] <= w0) lo = mid; else hi = mid;
       }
-      int b = lo, pos = w0, stepno = 0;
-      while (pos < w1) {
-        int be = bstart[b + 1];
+      wb = lo;
+    }
+    for (;;) {
+      int b, pos, be;
+      if (hot_phase) {
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= hot_total) { hot_phase = false; continue; }
+        int i = 0;
+        while (cx.hot_pre[i + 1] <= t) i++;
+        b = cx.hot_bucket[i];
+        const int bs = bstart[b] > r0 ? bstart[b] : r0;
+        const int bend = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        const int al = bs & ~(WSTEP - 1);
+        const int j = t - cx.hot_pre[i];
+        pos = al + j * SEG_ROWS;
+        if (pos < bs) pos = bs;
+        be = al + (j + 1) * SEG_ROWS;
+        if (be > bend) be = bend;
+      } else {
+        if (wpos >= w1) break;
+        be = bstart[wb + 1];
         if (be > w1) be = w1;
-        if (be > pos) {
+        if (be <= wpos) { wb++; continue; }
+        b = wb;
+        pos = wpos;
+        wpos = be;
+        wb++;
+        if (cx.is_hot(b)) continue;
+      }
+      {
+        {
           const LT l0v = lut[b];  // subspace 0's table starts the packed LUT
           float l0[QB];
 #pragma unroll
@@ -1183,9 +1348,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
               }
             }
           }
-          pos = be;
         }
-        b++;
       }
     }
   }
@@ -1231,7 +1394,7 @@ size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, 
   size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
   lut = (lut + 15) & ~(size_t)15;
   const size_t sb = ((size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8 + 15) & ~(size_t)15;
-  return lut + (size_t)qb * sb + (size_t)nwaves * qcap * 4 * (1 + qb);
+  return lut + (size_t)qb * sb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
 }
 
 template <typename K>

@@ -84,7 +84,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 32;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -269,6 +269,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.perm = ix->d_perm.as<uint32_t>();
     sp.bucket_start = ix->d_bstart.as<int>();
     sp.n_buckets = 1 << ix->bits[0];
+    sp.n_hot = 0;
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
     sp.nq = n;
@@ -303,6 +304,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.slice_rows = pl.slice_rows;
     sp.slice_stride = pl.slice_rows;
     sp.share_thr = pl.n_slices > 1;
+    // best-first buckets pay when a workgroup's slice spans many buckets
+    sp.n_hot = (ix->opt_hot && sp.n_buckets >= 16 && sp.n_buckets <= 4096 &&
+                pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
     const int lists = ix->N > 0 ? pl.n_slices : 0;
@@ -786,6 +790,9 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "early_abandon") {
     if (value < 0 || value > 3) return fail(VAQHIP_EINVAL, "early_abandon must be 0..3");
     ix->opt_ea = (int)value;
+  } else if (k == "hot_buckets") {
+    if (value < 0 || value > 32) return fail(VAQHIP_EINVAL, "hot_buckets must be 0..32");
+    ix->opt_hot = (int)value;
   } else if (k == "seed_thresholds") {
     ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
