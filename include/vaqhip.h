@@ -179,7 +179,7 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *   "timing"            1: record hipEvents (on the search's own stream) around
  *                       each kernel of every following search, up to 256
  *                       searches between two vaqhip_last_timing reads
- *   "hot_buckets"       0..32 (default 32): buckets (rows sharing their first code) each
+ *   "hot_buckets"       0..32 (default 16): buckets (rows sharing their first code) each
  *                       workgroup scans best-first, closest first term first, before
  *                       the rest of its slice; 0 = natural order only
  *   "waves_per_workgroup" 0 = auto (most wavefronts per CU), else 4, 8 or 16

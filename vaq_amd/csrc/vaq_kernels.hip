@@ -554,10 +554,16 @@ constexpr int PREFETCH = VAQ_PREFETCH;  // items loaded ahead of the one being p
 constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
 constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
 constexpr int THR_GLOBAL_EVERY = 64;
-constexpr int HOT_MAX = 32;            // buckets scanned best-first
+#ifndef VAQ_HOT_MAX
+#define VAQ_HOT_MAX 32
+#endif
+constexpr int HOT_MAX = VAQ_HOT_MAX;   // buckets scanned best-first
 constexpr int HOT_MAX_BUCKETS = 4096;  // best-first needs 1 << bits[0] <= this (rank scratch, mask)
 constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
-constexpr int HOT_SEG_STEPS = 16;      // wave steps per best-first work unit
+#ifndef VAQ_HOT_SEG
+#define VAQ_HOT_SEG 16
+#endif
+constexpr int HOT_SEG_STEPS = VAQ_HOT_SEG;  // wave steps per best-first work unit
 constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
 
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold

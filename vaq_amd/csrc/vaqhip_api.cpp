@@ -84,7 +84,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 32;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -128,7 +128,10 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   }
   // default queries per pass: 2 for byte codes (one ds_read_b64 serves both), 1 for the
   // bit-packed path (more whole buckets are skipped when only one query has to agree)
-  int qb = ix->opt_qb > 0 ? ix->opt_qb : (ix->layout == vaq::LAYOUT_BYTES ? 2 : 1);
+  // ... and 1 as well for byte codes that stay cache-resident (<= 128 MB): sharing the code
+  // stream between two queries buys nothing there, per-query bucket skipping does
+  const bool resident = (double)ix->N * ((ix->total_bits + 7) / 8) <= 128e6;
+  int qb = ix->opt_qb > 0 ? ix->opt_qb : ((ix->layout == vaq::LAYOUT_BYTES && !resident) ? 2 : 1);
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
   // the selection state are per workgroup, the survivor queues per wave; a CU

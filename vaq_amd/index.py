@@ -211,16 +211,23 @@ class VaqHip:
         _lib.check(fn(self._h, _ptr(X), nq, k, _ptr(ret.labels), _ptr(ret.distances)))
         return ret
 
-    def search_device(self, d_queries, k: int, projected: bool = False):
+    def search_device(self, d_queries, k: int, projected: bool = False, out=None):
         """Device-resident variant: torch CUDA tensors in and out, enqueued on
-        torch's current stream (no host copies, no synchronisation)."""
+        torch's current stream (no host copies, no synchronisation).  out =
+        (labels int32 [nq,k], distances float32 [nq,k]) reuses caller buffers, so a
+        steady-state loop performs no allocation at all."""
         import torch
         self._ensure_codes()
         q = d_queries.contiguous()
         assert q.is_cuda and q.dtype == torch.float32 and q.shape[1] == self.mTotalDim
         nq = q.shape[0]
-        labels = torch.empty((nq, k), dtype=torch.int32, device=q.device)
-        dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        if out is not None:
+            labels, dists = out
+            assert labels.shape == (nq, k) and labels.dtype == torch.int32 and labels.is_contiguous()
+            assert dists.shape == (nq, k) and dists.dtype == torch.float32 and dists.is_contiguous()
+        else:
+            labels = torch.empty((nq, k), dtype=torch.int32, device=q.device)
+            dists = torch.empty((nq, k), dtype=torch.float32, device=q.device)
         st = torch.cuda.current_stream(q.device).cuda_stream
         _lib.check(_lib.load().vaqhip_search_device(
             self._h, C.c_void_p(q.data_ptr()), nq, k, 1 if projected else 0,
@@ -317,7 +324,7 @@ class VaqHip:
             pass
 
 
-def merge_topk_device(dist_lists, label_lists, k: int):
+def merge_topk_device(dist_lists, label_lists, k: int, out=None):
     """Multi-GPU exchange step: [n_lists, nq, k] CUDA tensors (labels global,
     empty slots -1 / FLT_MAX) -> per-query k smallest by (distance, label)."""
     import torch
@@ -325,8 +332,11 @@ def merge_topk_device(dist_lists, label_lists, k: int):
     l = label_lists.contiguous()
     n_lists, nq, kk = d.shape
     assert kk == k and l.shape == d.shape and l.dtype == torch.int32 and d.dtype == torch.float32
-    out_l = torch.empty((nq, k), dtype=torch.int32, device=d.device)
-    out_d = torch.empty((nq, k), dtype=torch.float32, device=d.device)
+    if out is not None:
+        out_l, out_d = out
+    else:
+        out_l = torch.empty((nq, k), dtype=torch.int32, device=d.device)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=d.device)
     st = torch.cuda.current_stream(d.device).cuda_stream
     dev = d.device.index if d.device.index is not None else torch.cuda.current_device()
     _lib.check(_lib.load().vaqhip_merge_topk_device(

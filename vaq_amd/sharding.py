@@ -43,7 +43,7 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def gather_and_merge(labels, dists, k: int, merge_fn: Callable, group=None):
+def gather_and_merge(labels, dists, k: int, merge_fn: Callable, group=None, bufs=None):
     """labels/dists: this rank's [nq, k] result (global labels, empty slots
     -1 / FLT_MAX).  Returns the merged [nq, k] result (identical on all ranks).
     merge_fn(dist_lists[world, nq, k], label_lists[world, nq, k], k) -> (labels, dists)."""
@@ -52,14 +52,17 @@ def gather_and_merge(labels, dists, k: int, merge_fn: Callable, group=None):
     world = dist.get_world_size(group)
     nq = labels.shape[0]
     # concatenation along dim 0 ([world*nq, k]) is the layout every backend accepts
-    gl = torch.empty((world * nq, k), dtype=labels.dtype, device=labels.device)
-    gd = torch.empty((world * nq, k), dtype=dists.dtype, device=dists.device)
+    if bufs is not None:
+        gl, gd = bufs  # caller-owned [world*nq, k] buffers: no allocation in the loop
+    else:
+        gl = torch.empty((world * nq, k), dtype=labels.dtype, device=labels.device)
+        gd = torch.empty((world * nq, k), dtype=dists.dtype, device=dists.device)
     dist.all_gather_into_tensor(gl, labels.contiguous(), group=group)
     dist.all_gather_into_tensor(gd, dists.contiguous(), group=group)
     return merge_fn(gd.view(world, nq, k), gl.view(world, nq, k), k)
 
 
-def gather_query_slices(labels, dists, nq_total: int, group=None):
+def gather_query_slices(labels, dists, nq_total: int, group=None, bufs=None):
     """Query sharding: this rank answered queries [lo, hi) = shard_bounds(nq_total,
     world, rank) against ALL rows.  All-gathers the disjoint slices into the full
     [nq_total, k] result on every rank (slices are padded to ceil(nq/world) rows)."""
@@ -68,12 +71,18 @@ def gather_query_slices(labels, dists, nq_total: int, group=None):
     world = dist.get_world_size(group)
     per = (nq_total + world - 1) // world
     k = labels.shape[1]
-    pl = torch.full((per, k), -1, dtype=labels.dtype, device=labels.device)
-    pd = torch.zeros((per, k), dtype=dists.dtype, device=dists.device)
-    pl[: labels.shape[0]] = labels
-    pd[: dists.shape[0]] = dists
-    gl = torch.empty((world * per, k), dtype=labels.dtype, device=labels.device)
-    gd = torch.empty((world * per, k), dtype=dists.dtype, device=dists.device)
+    if labels.shape[0] == per:
+        pl, pd = labels.contiguous(), dists.contiguous()
+    else:  # short last slice: pad to the common length
+        pl = torch.full((per, k), -1, dtype=labels.dtype, device=labels.device)
+        pd = torch.zeros((per, k), dtype=dists.dtype, device=dists.device)
+        pl[: labels.shape[0]] = labels
+        pd[: dists.shape[0]] = dists
+    if bufs is not None:
+        gl, gd = bufs  # caller-owned [world*per, k]
+    else:
+        gl = torch.empty((world * per, k), dtype=labels.dtype, device=labels.device)
+        gd = torch.empty((world * per, k), dtype=dists.dtype, device=dists.device)
     dist.all_gather_into_tensor(gl, pl, group=group)
     dist.all_gather_into_tensor(gd, pd, group=group)
     return gl[:nq_total], gd[:nq_total]
