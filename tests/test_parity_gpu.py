@@ -93,14 +93,16 @@ def test_search_matches_oracle(vaqlib, oracle, cfg):
     o_lut = np.stack([oracle.create_lut(Xp[q], c["cents"], max(bits)) for q in range(nq)])
     assert np.array_equal(lut.view(np.uint32), o_lut.view(np.uint32))
     ties = 0
-    for qb, slices, ea in [(1, 0, 1), (2, 0, 1), (4, 0, 1), (2, 1, 1), (2, 3, 1), (1, 7, 1),
-                           (2, 0, 0), (4, 3, 0), (1, 1, 0), (2, 0, 2), (1, 5, 2), (4, 1, 2)]:
+    for qb, slices, ea, hot in [(1, 0, 1, 16), (2, 0, 1, 16), (4, 0, 1, 32), (2, 1, 1, 0), (2, 3, 1, 5),
+                                (1, 7, 1, 16), (2, 0, 0, 16), (4, 3, 0, 0), (1, 1, 0, 16), (2, 0, 2, 16),
+                                (1, 5, 2, 32), (4, 1, 2, 1), (1, 1, 1, 32), (1, 1, 2, 0)]:
         v.set_option("queries_per_pass", qb)
         v.set_option("slices", slices)
         v.set_option("early_abandon", ea)
+        v.set_option("hot_buckets", hot)
         ans = v.search(c["X"], k)
         ties += assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), o_lab, o_dis,
-                                    ad, what=f"cfg{seed} qb={qb} slices={slices} ea={ea}")
+                                    ad, what=f"cfg{seed} qb={qb} slices={slices} ea={ea} hot={hot}")
     if kw.get("integer"):
         assert ties > 0  # the boundary-tie rule was exercised
 
@@ -186,6 +188,7 @@ def test_full_size_properties(vaqlib):
         v.set_option("queries_per_pass", qb)
         v.set_option("early_abandon", ea)
         v.set_option("slices", sl)
+        v.set_option("hot_buckets", 0 if (qb, ea, sl) == (2, 1, 0) else 16)
         a = v.search(c["X"], k)
         res[(qb, ea, sl)] = (a.labels.reshape(64, k).copy(), a.distances.reshape(64, k).copy())
     v.set_option("slices", 0)
