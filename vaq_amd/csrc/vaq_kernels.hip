@@ -236,21 +236,24 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 }
 
 // ---------------------------------------------------------------------------
-// Bucketed row order.  The index stores rows stably sorted by the code of
-// subspace 0 -- after PCA the highest-variance subspace -- so that all rows of
-// a bucket share the first LUT term: the scan reads that term once per bucket
-// (wave-uniform) and skips a whole bucket, without touching its codes, when the
-// term alone already exceeds the threshold of every query in the batch (the
-// bucket-level form of VAQ::searchEarlyAbandon's test, VAQ.cpp:1708).
+// Bucketed row order.  The index stores rows stably sorted by (the top bits
+// of) the code of subspace 0 -- after PCA the highest-variance subspace.  A
+// bucket's rows share the first LUT term (shift == 0) or at least a lower bound
+// of it (shift > 0: the minimum over the bucket's 1 << shift codes), so the scan
+// skips a whole bucket, without touching its codes, when that bound alone already
+// exceeds the threshold of every query in the batch (the bucket-level form of
+// VAQ::searchEarlyAbandon's test, VAQ.cpp:1708); with shift == 0 it also reads
+// the term once per bucket (wave-uniform) instead of gathering it per row.
+// The host picks shift so that buckets average >= ~2048 rows.
 //   perm[r]          original row of sorted row r (labels are original rows)
 //   bucket_start[b]  first sorted row whose code 0 is >= b  (b = 0 .. K0)
 // ---------------------------------------------------------------------------
 __global__ void first_code_keys_kernel(const uint16_t *__restrict__ codes, int64_t n, int M,
-                                       unsigned mask, uint16_t *__restrict__ keys,
+                                       unsigned mask, int shift, uint16_t *__restrict__ keys,
                                        uint32_t *__restrict__ idx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = (uint16_t)(codes[i * M] & mask);
+  keys[i] = (uint16_t)((codes[i * M] & mask) >> shift);
   idx[i] = (uint32_t)i;
 }
 
@@ -261,9 +264,9 @@ __global__ void bucket_bounds_kernel(const uint16_t *__restrict__ keys, int64_t 
   if (i == 0 || keys[i] != keys[i - 1]) start[keys[i]] = (int)i;
 }
 
-hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, uint32_t *d_perm,
-                              int *d_bucket_start, hipStream_t st) {
-  const int K0 = 1 << bits0;
+hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift,
+                              uint32_t *d_perm, int *d_bucket_start, hipStream_t st) {
+  const int K0 = 1 << (bits0 - shift);  // buckets: the first code's top bits0 - shift bits
   hipError_t e = hipMemsetAsync(d_bucket_start, 0xff, (size_t)(K0 + 1) * sizeof(int), st);
   if (e != hipSuccess || n == 0) return e;
   uint16_t *keys_in = nullptr, *keys_out = nullptr;
@@ -280,14 +283,14 @@ hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bit
   }
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(first_code_keys_kernel, dim3(blocks), dim3(256), 0, st, d_codes, n, M,
-                     (unsigned)(K0 - 1), keys_in, idx_in);
+                     (unsigned)((1 << bits0) - 1), shift, keys_in, idx_in);
   // stable LSD radix sort on the b0 key bits: equal codes keep ascending original rows
   e = rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
-                                (unsigned)bits0, st);
+                                (unsigned)(bits0 - shift), st);
   if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
   if (e == hipSuccess)
     e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
-                                  (unsigned)bits0, st);
+                                  (unsigned)(bits0 - shift), st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, d_bucket_start);
     e = hipGetLastError();
@@ -586,6 +589,8 @@ template <int QB> struct ScanCtx {
   // best-first phase: the n_hot buckets whose first term is smallest for this
   // query batch are scanned before the rest (so the thresholds are near-final
   // when the remaining buckets are tested for skipping)
+  LT *lb;              // [n_buckets] per-bucket lower bound of the first term (== lut when shift == 0)
+  int bshift;          // bucket = first code >> bshift
   int *hot_bucket;     // [HOT_MAX] bucket ids in ascending-key order, -1 = none
   int *hot_pre;        // [HOT_MAX + 1] prefix of segment counts
   unsigned *hot_mask;  // [HOT_MASK_WORDS] bit b set = bucket b is handled by the hot phase
@@ -609,11 +614,14 @@ template <int QB> struct ScanCtx {
         const int s0 = bstart[b] > r0 ? bstart[b] : r0;
         const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
         if (e0 > s0) {
-          float m = p.lut[(size_t)qi[0] * p.lut_floats + b];
+          // smallest first term any row of the bucket can have, over the batch's queries
+          float m = INFINITY;
+          for (int c = b << p.bucket_shift; c < ((b + 1) << p.bucket_shift); c++) {
 #pragma unroll
-          for (int q = 1; q < QB; q++) {
-            const float x = p.lut[(size_t)qi[q] * p.lut_floats + b];
-            m = x < m ? x : m;
+            for (int q = 0; q < QB; q++) {
+              const float x = p.lut[(size_t)qi[q] * p.lut_floats + c];
+              m = x < m ? x : m;
+            }
           }
           key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
           if (m != m) key = 0xffffffffu;
@@ -702,6 +710,9 @@ template <int QB> struct ScanCtx {
     }
     off += QB * sb;
     n_hot = p.n_hot;
+    bshift = p.bucket_shift;
+    lb = bshift > 0 ? reinterpret_cast<LT *>(smem + off) : lut;
+    if (bshift > 0) off += ((size_t)p.n_buckets * sizeof(LT) + 15) & ~(size_t)15;
     hot_bucket = reinterpret_cast<int *>(smem + off);
     hot_pre = hot_bucket + HOT_MAX;
     hot_mask = reinterpret_cast<unsigned *>(hot_pre + HOT_MAX + 1);
@@ -720,6 +731,19 @@ template <int QB> struct ScanCtx {
 #pragma unroll
       for (int q = 0; q < QB; q++) lv_set<QB>(val, q, p.lut[(size_t)qi[q] * p.lut_floats + e]);
       lut[e] = val;
+    }
+    if (bshift > 0) {  // per-bucket lower bounds of the first term
+      __syncthreads();
+      for (int b = tid; b < p.n_buckets; b += nthreads) {
+        LT m = lut[b << bshift];
+        for (int c = (b << bshift) + 1; c < ((b + 1) << bshift); c++) {
+          const LT x = lut[c];
+#pragma unroll
+          for (int q = 0; q < QB; q++)
+            if (lv_get<QB>(x, q) < lv_get<QB>(m, q)) lv_set<QB>(m, q, lv_get<QB>(x, q));
+        }
+        lb[b] = m;
+      }
     }
   }
 
@@ -1042,8 +1066,8 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
       }
       {
         {
-          // the bucket's first term, dism = l0, is wave-uniform
-          const LT l0v = lut[b];
+          // the bucket's first term dism = l0 (or its lower bound) is wave-uniform
+          const LT l0v = cx.lb[b];
           float l0[QB];
 #pragma unroll
           for (int q = 0; q < QB; q++)
@@ -1067,11 +1091,16 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
               // A: dism = l0; dism += l1, every row of the item, all lanes
               float part[Item::ROWS][QB];
               bool alive[Item::ROWS];
+              if (cx.bshift == 0) {
 #pragma unroll
-              for (int r = 0; r < Item::ROWS; r++) {
+                for (int r = 0; r < Item::ROWS; r++) {
 #pragma unroll
-                for (int q = 0; q < QB; q++) part[r][q] = l0[q];
-                group_sum(cur.word(r, 0), 0, 1, PHASE_A_SUBS, part[r]);
+                  for (int q = 0; q < QB; q++) part[r][q] = l0[q];
+                  group_sum(cur.word(r, 0), 0, 1, PHASE_A_SUBS, part[r]);
+                }
+              } else {  // coarse buckets: the first term is gathered per row
+#pragma unroll
+                for (int r = 0; r < Item::ROWS; r++) group_sum(cur.word(r, 0), 0, 0, PHASE_A_SUBS, part[r]);
               }
 #pragma unroll
               for (int r = 0; r < Item::ROWS; r++)
@@ -1261,6 +1290,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
     const int w1 = (w0 + per_wave < r1) ? w0 + per_wave : r1;
     const int *__restrict__ bstart = p.bucket_start;
     // subspaces 1..3 complete the first group (sequential mode may have fewer than 4)
+    const SubDesc s0c = sub[0];
     const SubDesc s1 = sub[M > 1 ? 1 : 0], s2 = sub[M > 2 ? 2 : 0], s3 = sub[M > 3 ? 3 : 0];
     constexpr int WSTEP = TILE_ROWS;
     constexpr int SEG_ROWS = HOT_SEG_STEPS * WSTEP;
@@ -1306,7 +1336,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
       }
       {
         {
-          const LT l0v = lut[b];  // subspace 0's table starts the packed LUT
+          const LT l0v = cx.lb[b];  // first term (or its lower bound); subspace 0's table starts the packed LUT
           float l0[QB];
 #pragma unroll
           for (int q = 0; q < QB; q++)
@@ -1331,6 +1361,8 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
               float acc[QB], dism[QB];
 #pragma unroll
               for (int q = 0; q < QB; q++) { acc[q] = l0[q]; dism[q] = l0[q]; }  // dism = l0 / dist = l0
+              if (cx.bshift > 0)  // coarse buckets: gather the row's own first term
+                chain(0, lut[w0w & (unsigned)(s0c.ncent - 1)], acc, dism);
               // A: dism += l1 (field 1 lies inside dword 0)
               if (M > 1)
                 chain(1, lut[s1.lut_off + ((w0w >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
@@ -1394,13 +1426,15 @@ void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qc
   *qcap = ea == EA_QUEUE ? 64 + 64 * rows_per_item(layout, M) : 0;
 }
 
-size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves) {
+size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves,
+                      int n_buckets, int bucket_shift) {
   int kp, ccap, qcap;
   scan_geometry(layout, M, k, ea, &kp, &ccap, &qcap);
   size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
   lut = (lut + 15) & ~(size_t)15;
   const size_t sb = ((size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8 + 15) & ~(size_t)15;
-  return lut + (size_t)qb * sb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
+  const size_t lbb = bucket_shift > 0 ? (((size_t)n_buckets * 4 * qb + 15) & ~(size_t)15) : 0;
+  return lut + (size_t)qb * sb + lbb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
 }
 
 template <typename K>
@@ -1434,7 +1468,8 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
-  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.k, p.ea, p.nwaves);
+  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
+                                   p.bucket_shift);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes, 8)

@@ -79,6 +79,7 @@ struct vaqhip_index {
   DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
   bool has_eig = false;
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
+  int bucket_shift = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
@@ -142,7 +143,8 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   for (;;) {
     for (int nw : {4, 8, 16}) {
       if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
-      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, nw);
+      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, nw, ix->n_buckets,
+                                                  ix->bucket_shift);
       if (lds > LDS_LIMIT) continue;
       const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
       if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
@@ -158,7 +160,8 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   pl->ea = ea;
   pl->nwaves = best_nw;
   vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
-  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, best_nw);
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, best_nw, ix->n_buckets,
+                                ix->bucket_shift);
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const int64_t N = ix->N;
   const int nqb = (nq + qb - 1) / qb;
@@ -271,7 +274,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.first_sub = ix->d_first_sub.as<int>();
     sp.perm = ix->d_perm.as<uint32_t>();
     sp.bucket_start = ix->d_bstart.as<int>();
-    sp.n_buckets = 1 << ix->bits[0];
+    sp.n_buckets = ix->n_buckets;
+    sp.bucket_shift = ix->bucket_shift;
     sp.n_hot = 0;
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
@@ -475,7 +479,14 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
   HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
   const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
-  const int K0 = 1 << ix->bits[0];
+  // bucket = top bits of the first code, coarse enough that buckets average >= ~2048 rows
+  // (at most 4096 buckets; at most 1024 when coarser than the code itself)
+  int kb = ix->bits[0];
+  while (kb > 4 && ((int64_t)1 << kb) * 2048 > std::max<int64_t>(N, 1)) kb--;
+  if (kb > 12) kb = 12;
+  if (kb < ix->bits[0] && kb > 10) kb = 10;
+  const int shift = ix->bits[0] - kb;
+  const int K0 = 1 << kb;
   HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
   HIP_TRY(ix->d_perm.ensure(std::max<size_t>((size_t)N, 1) * sizeof(uint32_t)));
   std::vector<int> bstart((size_t)K0 + 1, (int)N);
@@ -494,7 +505,7 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
       }
       d_u16 = staged.as<uint16_t>();
     }
-    HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], ix->d_perm.as<uint32_t>(),
+    HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->d_perm.as<uint32_t>(),
                                     ix->d_bstart.as<int>(), st));
     HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
     bstart[K0] = (int)N;
@@ -507,6 +518,8 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
   ix->N = N;
   ix->id_base = id_base;
+  ix->bucket_shift = shift;
+  ix->n_buckets = K0;
   return VAQHIP_OK;
 }
 
