@@ -188,24 +188,29 @@ def main():
         v.set_option("hot_buckets", args.hot)
     info = v.info()
 
-    # every buffer of the steady-state loop is allocated once, here
-    out_local = (torch.empty((nq_local, k), dtype=torch.int32, device=dev),
-                 torch.empty((nq_local, k), dtype=torch.float32, device=dev))
+    # every buffer of the steady-state loop is allocated once, here; with several ranks the
+    # labels and distances of a rank travel in ONE all-gather (packed [2, n, k] int32 buffer)
     per_q = (nq + world - 1) // world
-    gather_rows = world * (nq if mode == "rows" else per_q)
-    gbufs = (torch.empty((gather_rows, k), dtype=torch.int32, device=dev),
-             torch.empty((gather_rows, k), dtype=torch.float32, device=dev)) if world > 1 else None
+    n_pack = nq if mode == "rows" else per_q
+    pack_local, lab_view, dis_view = sharding.make_packed(n_pack, k, dev)
+    out_local = (lab_view[:nq_local], dis_view[:nq_local])
+    if nq_local < n_pack:  # short last query slice: the padding rows stay empty
+        lab_view[nq_local:].fill_(-1)
+        dis_view[nq_local:].fill_(3.4028234663852886e38)
+    gathered = torch.empty((world, 2, n_pack, k), dtype=torch.int32, device=dev) if world > 1 else None
     out_final = (torch.empty((nq, k), dtype=torch.int32, device=dev),
                  torch.empty((nq, k), dtype=torch.float32, device=dev)) if world > 1 else None
+    from vaq_amd.index import merge_topk_packed_device
 
     def run_step():
         l, d = v.search_device(my_queries, k, out=out_local)
         if world > 1:
+            sharding.all_gather_packed(pack_local, gathered)
             if mode == "rows":
-                l, d = sharding.gather_and_merge(
-                    l, d, k, lambda gd, gl, kk: merge_topk_device(gd, gl, kk, out=out_final), bufs=gbufs)
-            else:
-                l, d = sharding.gather_query_slices(l, d, nq, bufs=gbufs)
+                l, d = merge_topk_packed_device(gathered, world, nq, k, out=out_final)
+            else:  # disjoint query slices: the gathered planes ARE the result (strided views)
+                l = gathered[:, 0].reshape(world * per_q, k)[:nq]
+                d = gathered[:, 1].reshape(world * per_q, k)[:nq].view(torch.float32)
         return l, d
 
     log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")

@@ -157,6 +157,15 @@ int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists,
                              const int32_t *d_label_lists, int n_lists, int nq, int k,
                              int32_t *d_labels_out, float *d_dist_out, void *stream);
 
+/* Same with explicit element strides: candidate i of list l of query q is read at
+ * d_dist_lists[l*list_stride + q*query_stride + i] (labels likewise), so the lists may
+ * sit inside one packed all-gather buffer (labels and distances gathered by a single
+ * collective: vaq_amd/sharding.py). */
+int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
+                                     const int32_t *d_label_lists, int n_lists,
+                                     int64_t list_stride, int64_t query_stride, int nq, int k,
+                                     int32_t *d_labels_out, float *d_dist_out, void *stream);
+
 /* ----- introspection / tuning -------------------------------------------- */
 typedef struct {
   int D, M, L;

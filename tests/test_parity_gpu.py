@@ -216,6 +216,11 @@ def test_full_size_properties(vaqlib):
     torch.cuda.synchronize()
     ml, md = merge_topk_device(torch.stack(parts_d), torch.stack(parts_l), k)
     assert np.array_equal(ml.cpu().numpy(), lab) and np.array_equal(md.cpu().numpy(), dis)
+    # the one-collective layout: [world, 2, nq, k] int32 (labels plane, distance-bits plane)
+    from vaq_amd.index import merge_topk_packed_device
+    packed = torch.stack([torch.stack([parts_l[i], parts_d[i].view(torch.int32)]) for i in range(2)]).contiguous()
+    pl, pd = merge_topk_packed_device(packed, 2, 64, k)
+    assert np.array_equal(pl.cpu().numpy(), lab) and np.array_equal(pd.cpu().numpy(), dis)
 
 
 def test_cpp_demo_driver(vaqlib, oracle, tmp_path):

@@ -119,6 +119,40 @@ def test_two_rank_query_sharding(oracle, nq):
     assert ret.get(timeout=5) == "ok"
 
 
+def _worker_packed(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vaq_amd import sharding
+    n, k = 5, 3
+    buf, lab, dis = sharding.make_packed(n, k, "cpu")
+    lab.copy_(torch.arange(n * k, dtype=torch.int32).view(n, k) + 100 * rank)
+    dis.copy_(torch.arange(n * k, dtype=torch.float32).view(n, k) * 0.5 + rank)
+    g = torch.empty((world, 2, n, k), dtype=torch.int32)
+    sharding.all_gather_packed(buf, g)
+    for r in range(world):
+        assert torch.equal(g[r, 0], torch.arange(n * k, dtype=torch.int32).view(n, k) + 100 * r)
+        assert torch.equal(g[r, 1].view(torch.float32), torch.arange(n * k, dtype=torch.float32).view(n, k) * 0.5 + r)
+    if rank == 0:
+        ret.put("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_packed_all_gather():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == "ok"
+
+
 def test_choose_mode():
     from vaq_amd.sharding import choose_mode
     assert choose_mode(1_000_000, 8, 10_000, 8) == "queries"        # C2: 8 MB of codes, plenty of queries

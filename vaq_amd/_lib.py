@@ -16,6 +16,7 @@ SYMBOLS = [
     "vaqhip_index_create", "vaqhip_index_create_ex", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
     "vaqhip_index_set_codes_u16_device", "vaqhip_search", "vaqhip_search_projected",
     "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
+    "vaqhip_merge_topk_strided_device",
     "vaqhip_encode", "vaqhip_encode_device", "vaqhip_refine", "vaqhip_refine_device",
     "vaqhip_index_info", "vaqhip_set_option", "vaqhip_last_timing", "vaqhip_last_error",
     "vaqhip_version", "vaqhip_device_count",
@@ -94,6 +95,7 @@ def load():
     L.vaqhip_encode_device.argtypes = [vp, vp, i64, i32, vp, vp]
     L.vaqhip_refine.argtypes = [i32, vp, i32, i32, vp, i64, vp, i32, i32, vp, vp]
     L.vaqhip_refine_device.argtypes = [i32, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.vaqhip_merge_topk_strided_device.argtypes = [i32, vp, vp, i32, i64, i64, i32, i32, vp, vp, vp]
     L.vaqhip_index_info.argtypes = [vp, C.POINTER(Info)]
     L.vaqhip_set_option.argtypes = [vp, C.c_char_p, i64]
     L.vaqhip_last_timing.argtypes = [vp, C.POINTER(Timing)]

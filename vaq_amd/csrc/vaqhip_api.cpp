@@ -645,6 +645,14 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int project
 int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists, const int32_t *d_label_lists,
                              int n_lists, int nq, int k, int32_t *d_labels_out, float *d_dist_out,
                              void *stream) {
+  return vaqhip_merge_topk_strided_device(device_id, d_dist_lists, d_label_lists, n_lists,
+                                          (int64_t)nq * k, k, nq, k, d_labels_out, d_dist_out, stream);
+}
+
+int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
+                                     const int32_t *d_label_lists, int n_lists, int64_t list_stride,
+                                     int64_t query_stride, int nq, int k, int32_t *d_labels_out,
+                                     float *d_dist_out, void *stream) {
   if (n_lists < 0 || nq < 0 || k <= 0) return fail(VAQHIP_EINVAL, "bad sizes");
   if (k > VAQHIP_MAX_K) return fail(VAQHIP_EUNSUPPORTED, "k=%d > %d", k, VAQHIP_MAX_K);
   if (nq == 0) return VAQHIP_OK;
@@ -653,7 +661,8 @@ int vaqhip_merge_topk_device(int device_id, const float *d_dist_lists, const int
   DeviceGuard g(device_id);
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
   if (n_lists > 16) return fail(VAQHIP_EUNSUPPORTED, "at most 16 lists per merge");
-  HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, n_lists, (int64_t)nq * k, k, nq, k, 0, 1,
+  if (list_stride < 0 || query_stride < 0) return fail(VAQHIP_EINVAL, "negative stride");
+  HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, n_lists, list_stride, query_stride, nq, k, 0, 1,
                             d_labels_out, d_dist_out, nullptr, nullptr, nullptr,
                             static_cast<hipStream_t>(stream)));
   return VAQHIP_OK;

@@ -343,3 +343,22 @@ def merge_topk_device(dist_lists, label_lists, k: int, out=None):
         dev, C.c_void_p(d.data_ptr()), C.c_void_p(l.data_ptr()), n_lists, nq, k,
         C.c_void_p(out_l.data_ptr()), C.c_void_p(out_d.data_ptr()), C.c_void_p(st)))
     return out_l, out_d
+
+
+def merge_topk_packed_device(packed, world: int, nq: int, k: int, out=None):
+    """packed: int32 CUDA tensor [world, 2, nq, k] from ONE all-gather -- plane 0 holds
+    labels, plane 1 the float32 distance bits.  Returns the merged (labels, distances)."""
+    import torch
+    assert packed.is_contiguous() and packed.dtype == torch.int32 and packed.numel() == world * 2 * nq * k
+    if out is not None:
+        out_l, out_d = out
+    else:
+        out_l = torch.empty((nq, k), dtype=torch.int32, device=packed.device)
+        out_d = torch.empty((nq, k), dtype=torch.float32, device=packed.device)
+    st = torch.cuda.current_stream(packed.device).cuda_stream
+    dev = packed.device.index if packed.device.index is not None else torch.cuda.current_device()
+    base = packed.data_ptr()
+    _lib.check(_lib.load().vaqhip_merge_topk_strided_device(
+        dev, C.c_void_p(base + nq * k * 4), C.c_void_p(base), world, 2 * nq * k, k, nq, k,
+        C.c_void_p(out_l.data_ptr()), C.c_void_p(out_d.data_ptr()), C.c_void_p(st)))
+    return out_l, out_d

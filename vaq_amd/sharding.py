@@ -86,3 +86,22 @@ def gather_query_slices(labels, dists, nq_total: int, group=None, bufs=None):
     dist.all_gather_into_tensor(gl, pl, group=group)
     dist.all_gather_into_tensor(gd, pd, group=group)
     return gl[:nq_total], gd[:nq_total]
+
+
+# ---------------------------------------------------------------------------
+# One-collective forms: labels and distances travel in ONE all-gather of a packed
+# int32 buffer [2, n, k] per rank (plane 0 labels, plane 1 float32 bits).  At
+# millisecond step times the second collective's launch latency is visible.
+# ---------------------------------------------------------------------------
+def make_packed(n: int, k: int, device):
+    """Per-rank result buffer; search writes into .labels / .dists views of it."""
+    import torch
+    buf = torch.empty((2, n, k), dtype=torch.int32, device=device)
+    return buf, buf[0], buf[1].view(torch.float32)
+
+
+def all_gather_packed(packed_local, gathered, group=None):
+    """gathered: int32 [world, 2, n, k] (caller-owned).  One collective."""
+    import torch.distributed as dist
+    dist.all_gather_into_tensor(gathered.view(-1), packed_local.view(-1), group=group)
+    return gathered
