@@ -67,6 +67,9 @@ struct ScanParams {
                           // larger for the sampling pre-pass)
   int share_thr;          // 1: exchange thresholds between workgroups through g_thr
   int seq;                // 1: sequential row sum (BitVecEngine::queryLUT) instead of groups of 4
+  int32_t *final_labels;  // non-null (needs n_slices == 1): results written directly, [nq][k]
+  float *final_dist;
+  int64_t id_base;
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
@@ -74,7 +77,7 @@ struct ScanParams {
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
                           hipStream_t st);
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,
-                            const SubDesc *sub, const float *cent, int lut_floats,
+                            const SubDesc *sub, const float *cent, int lut_floats, int max_ncent,
                             float *lut, hipStream_t st);
 hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDesc *sub,
                              int lut_floats, int ksub, float *lut_ref, hipStream_t st);

@@ -101,11 +101,14 @@ __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
   extern __shared__ float qs[];
   const int q = blockIdx.x, s = blockIdx.y;
   const SubDesc sd = sub[s];
+  if ((int)(blockIdx.z * blockDim.x) >= sd.ncent) return;  // chunk beyond this subspace's codebook
   for (int j = threadIdx.x; j < L; j += blockDim.x) qs[j] = qproj[(size_t)q * D + (size_t)s * L + j];
   __syncthreads();
   float *out = lut + (size_t)q * lut_floats + sd.lut_off;
   const float *cs = cent + sd.cent_off;
-  for (int c = threadIdx.x; c < sd.ncent; c += blockDim.x) {
+  // blockIdx.z selects a chunk of 256 centroids, so a 4096-centroid subspace is spread
+  // over 16 workgroups instead of looping in one
+  for (int c = blockIdx.z * blockDim.x + threadIdx.x; c < sd.ncent; c += gridDim.z * blockDim.x) {
     const float *y = cs + (size_t)c * L;
     float r;
     if (sd.ncent >= 8) {
@@ -146,9 +149,14 @@ __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
 }
 
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L, const SubDesc *sub,
-                            const float *cent, int lut_floats, float *lut, hipStream_t st) {
+                            const float *cent, int lut_floats, int max_ncent, float *lut,
+                            hipStream_t st) {
   if (nq == 0) return hipSuccess;
-  hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M), dim3(256), L * sizeof(float), st, qproj, D, L,
+  // one workgroup per (query, subspace): splitting big codebooks over blockIdx.z was measured
+  // slower (the extra, mostly empty workgroups cost more than the 16-iteration loop they save)
+  (void)max_ncent;
+  const int chunks = 1;
+  hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M, chunks), dim3(256), L * sizeof(float), st, qproj, D, L,
                      sub, cent, lut_floats, lut);
   return hipGetLastError();
 }
@@ -850,10 +858,22 @@ template <int QB> struct ScanCtx {
       if (wave == (q % nwaves) && x < p.nq) {
         if (sel_fold(sel[q], k, kp, lane) && multi_slice && lane == 0)
           atomicMin(&g_thr[qi[q]], sel[q].hdr[SEL_THR_D]);
-        const size_t o = ((size_t)x * p.n_slices + slice) * k;
-        for (int i = lane; i < k; i += 64) {
-          p.part_d[o + i] = sel[q].d[i];
-          p.part_id[o + i] = sel[q].id[i];
+        if (p.final_labels) {
+          // one slice per query: this list IS the result -- write it in the API's
+          // format (heap_reorder's: ascending, empty slots -1 / FLT_MAX) and skip the merge
+          const size_t o = (size_t)x * k;
+          for (int i = lane; i < k; i += 64) {
+            const int id = sel[q].id[i];
+            const bool ok = id != ID_SENTINEL;
+            p.final_labels[o + i] = ok ? (int32_t)(id + p.id_base) : -1;
+            p.final_dist[o + i] = ok ? sel[q].d[i] : FLT_MAX;
+          }
+        } else {
+          const size_t o = ((size_t)x * p.n_slices + slice) * k;
+          for (int i = lane; i < k; i += 64) {
+            p.part_d[o + i] = sel[q].d[i];
+            p.part_id[o + i] = sel[q].id[i];
+          }
         }
       }
     }

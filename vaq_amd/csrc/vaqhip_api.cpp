@@ -262,7 +262,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent.as<float>(), ix->lut_floats, ix->w_lut.as<float>(), st));
+                                  ix->d_cent.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
     if (timing) HIP_TRY(hipEventRecord(ev[2], st));
     vaq::ScanParams sp;
     sp.codes = ix->d_codes.as<uint32_t>();
@@ -291,6 +291,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.qb = pl.qb;
     sp.part_d = ix->w_part_d.as<float>();
     sp.part_id = ix->w_part_id.as<int>();
+    sp.final_labels = nullptr;
+    sp.final_dist = nullptr;
+    sp.id_base = ix->id_base;
     int grid = 0;
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
@@ -311,15 +314,21 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.slice_rows = pl.slice_rows;
     sp.slice_stride = pl.slice_rows;
     sp.share_thr = pl.n_slices > 1;
+    const bool direct = pl.n_slices == 1 && ix->N > 0;  // the single list per query is the result
+    if (direct) {
+      sp.final_labels = d_labels + (size_t)q0 * k;
+      sp.final_dist = d_dist + (size_t)q0 * k;
+    }
     // best-first buckets pay when a workgroup's slice spans many buckets
     sp.n_hot = (ix->opt_hot && sp.n_buckets >= 16 && sp.n_buckets <= 4096 &&
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
     const int lists = ix->N > 0 ? pl.n_slices : 0;
-    HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, lists, k, (int64_t)pl.n_slices * k, n, k,
-                              ix->id_base, 0, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k,
-                              nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
+    if (!direct)
+      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, lists, k, (int64_t)pl.n_slices * k, n, k,
+                                ix->id_base, 0, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k,
+                                nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
     if (timing) HIP_TRY(hipEventRecord(ev[5], st));
     tm.seed_slices = pl.seed_slices;
     tm.queries_per_pass = pl.qb;
@@ -632,7 +641,7 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int project
       qp = ix->w_qproj.as<float>();
     }
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent.as<float>(), ix->lut_floats, ix->w_lut.as<float>(), st));
+                                  ix->d_cent.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
     HIP_TRY(vaq::launch_lut_expand(ix->w_lut.as<float>(), n, ix->M, ix->d_sub.as<vaq::SubDesc>(),
                                    ix->lut_floats, ksub, ix->w_lutref.as<float>(), st));
     HIP_TRY(hipMemcpyAsync(lut_out + (size_t)q0 * per_q, ix->w_lutref.p, (size_t)n * per_q * sizeof(float),
