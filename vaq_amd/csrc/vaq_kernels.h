@@ -70,6 +70,7 @@ struct ScanParams {
   int32_t *final_labels;  // non-null (needs n_slices == 1): results written directly, [nq][k]
   float *final_dist;
   int64_t id_base;
+  int *part_cnt;          // [nq][n_slices] real entries of each list
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
@@ -117,7 +118,8 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
 // More than 64 lists are folded in levels through scratch_d/scratch_id
 // (merge_scratch_elems() elements each).
 size_t merge_scratch_elems(int n_lists, int nq, int k);
-hipError_t launch_merge(const float *part_d, const int *part_id, int n_lists,
+// part_cnt (optional, scan partials only): real entries per list, [nq][n_lists]
+hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,
                         unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st);

@@ -874,6 +874,7 @@ template <int QB> struct ScanCtx {
             p.part_d[o + i] = sel[q].d[i];
             p.part_id[o + i] = sel[q].id[i];
           }
+          if (lane == 0) p.part_cnt[(size_t)x * p.n_slices + slice] = (int)sel[q].hdr[SEL_NBEST];
         }
       }
     }
@@ -954,6 +955,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave;
   __syncthreads();
+  cx.refresh(0);  // pick up the seeded / already published thresholds before the first bucket test
 
   const int step_items = nthreads;  // items per workgroup step
   const int64_t item0 = r0 / Item::ROWS + wave * 64 + lane;
@@ -1197,6 +1199,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
   __syncthreads();
+  cx.refresh(0);  // pick up the seeded / already published thresholds before the first bucket test
 
   const int64_t tile0 = r0 / TILE_ROWS + wave;
   const int n_steps = (r1 > r0) ? (r1 - r0 + nthreads - 1) / nthreads : 0;
@@ -1637,8 +1640,72 @@ hipError_t launch_refine(const float *Q, int nq, int D, const float *dataset, co
   return hipGetLastError();
 }
 
+// First merge level when the scan left MANY lists per query (one per row slice) that are
+// mostly empty because the thresholds were tight: grid = (query, group of 256 lists), one
+// thread per list; the per-list entry counts written by the scan let the workgroup gather
+// only real candidates -- usually a single sort -- instead of reading 256 x k slots.
+constexpr int MERGE_LPG = 256;
+
+__global__ __launch_bounds__(MERGE_THREADS) void merge_compact_kernel(
+    const float *__restrict__ part_d, const int *__restrict__ part_id,
+    const int *__restrict__ part_cnt, int n_lists, int k, int32_t *__restrict__ out_id,
+    float *__restrict__ out_d) {
+  __shared__ float sd[MERGE_CAP];
+  __shared__ int si[MERGE_CAP];
+  __shared__ int pre[MERGE_LPG + 1];
+  __shared__ int s_end;
+  const int q = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int l0 = g * MERGE_LPG;
+  const int nl = (n_lists - l0 < MERGE_LPG) ? n_lists - l0 : MERGE_LPG;
+  const int my = (tid < nl) ? part_cnt[(size_t)q * n_lists + l0 + tid] : 0;
+  // inclusive scan of the counts (Hillis-Steele over 256 entries)
+  pre[tid + 1] = my;
+  if (tid == 0) pre[0] = 0;
+  __syncthreads();
+  for (int off = 1; off < MERGE_LPG; off <<= 1) {
+    const int v = (tid >= off) ? pre[tid + 1 - off] : 0;
+    __syncthreads();
+    pre[tid + 1] += v;
+    __syncthreads();
+  }
+  int kept = 0, start = 0;
+  while (start < nl) {
+    const int room = MERGE_CAP - kept;
+    if (tid == 0) s_end = start + 1;  // one list always fits: counts <= k <= 1024 <= room
+    __syncthreads();
+    if (tid >= start && tid < nl && pre[tid + 1] - pre[start] <= room) atomicMax(&s_end, tid + 1);
+    __syncthreads();
+    const int end = s_end;
+    if (tid >= start && tid < end) {
+      const size_t src = ((size_t)q * n_lists + l0 + tid) * k;
+      const int dst = kept + pre[tid] - pre[start];
+      for (int i = 0; i < my; i++) {
+        sd[dst + i] = part_d[src + i];
+        si[dst + i] = part_id[src + i];
+      }
+    }
+    const int n = kept + pre[end] - pre[start];
+    int P = 2;
+    while (P < n) P <<= 1;
+    __syncthreads();
+    for (int i = n + tid; i < P; i += MERGE_THREADS) { sd[i] = INFINITY; si[i] = ID_SENTINEL; }
+    __syncthreads();
+    bitonic_sort<true>(sd, si, P, tid, MERGE_THREADS);
+    kept = n < k ? n : k;
+    start = end;
+    __syncthreads();
+  }
+  const size_t o = ((size_t)q * gridDim.y + g) * k;
+  for (int i = tid; i < k; i += MERGE_THREADS) {
+    const bool ok = i < kept && si[i] != ID_SENTINEL;
+    out_id[o + i] = ok ? si[i] : ID_SENTINEL;
+    out_d[o + i] = ok ? sd[i] : INFINITY;
+  }
+}
+
 size_t merge_scratch_elems(int n_lists, int nq, int k) {
   size_t lists = 1;  // room for one discarded result list (labels == nullptr)
+  // worst case of either first level (compacting groups of 256, or plain groups of 16)
   for (size_t n = (size_t)n_lists; n > (size_t)MERGE_FANIN;) {
     n = (n + MERGE_FANIN - 1) / MERGE_FANIN;
     lists += n;
@@ -1646,16 +1713,33 @@ size_t merge_scratch_elems(int n_lists, int nq, int k) {
   return lists * (size_t)nq * k;
 }
 
-hipError_t launch_merge(const float *part_d, const int *part_id, int n_lists, int64_t list_stride,
-                        int64_t query_stride, int nq, int k, int64_t id_base, int in_final,
-                        int32_t *labels, float *dist, unsigned *thr_out, float *scratch_d,
-                        int *scratch_id, hipStream_t st) {
+hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
+                        int64_t list_stride, int64_t query_stride, int nq, int k, int64_t id_base,
+                        int in_final, int32_t *labels, float *dist, unsigned *thr_out,
+                        float *scratch_d, int *scratch_id, hipStream_t st) {
   if (nq == 0 || k == 0) return hipSuccess;
   const float *cur_d = part_d;
   const int *cur_id = part_id;
   float *sd = scratch_d;
   int *si = scratch_id;
   if (!labels && (!sd || !si)) return hipErrorInvalidValue;
+  if (part_cnt && n_lists > MERGE_FANIN && list_stride == k && query_stride == (int64_t)n_lists * k) {
+    // scan partials with per-list counts: compact 256 lists per workgroup first
+    const int groups = (n_lists + MERGE_LPG - 1) / MERGE_LPG;
+    if (!sd || !si) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_compact_kernel, dim3(nq, groups), dim3(MERGE_THREADS), 0, st, cur_d, cur_id,
+                       part_cnt, n_lists, k, si, sd);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    cur_d = sd;
+    cur_id = si;
+    sd += (size_t)nq * groups * k;
+    si += (size_t)nq * groups * k;
+    n_lists = groups;
+    list_stride = k;
+    query_stride = (int64_t)groups * k;
+    in_final = 0;
+  }
   // fold 64 lists at a time into intermediate lists until one workgroup can finish
   while (n_lists > MERGE_FANIN) {
     const int groups = (n_lists + MERGE_FANIN - 1) / MERGE_FANIN;

@@ -64,7 +64,6 @@ constexpr int QUERY_CHUNK = 16384;             // queries per internal launch se
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
 constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short to need seeding
-constexpr int64_t SEED_FRACTION = 64;          // the pre-pass scans N / 64 rows
 constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
 constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to which EA_INPLACE is chosen
 
@@ -82,10 +81,10 @@ struct vaqhip_index {
   int bucket_shift = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
-  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -188,7 +187,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   pl->seed_slices = 0;
   pl->seed_rows = pl->seed_stride = 0;
   if (ea && ix->opt_seed && s >= SEED_MIN_SLICES && N >= SEED_MIN_ROWS) {
-    const int64_t sample = std::max<int64_t>(N / SEED_FRACTION, (int64_t)16 * k);
+    const int64_t sample = std::max<int64_t>(N / ix->opt_seed_frac, (int64_t)16 * k);
     // small workgroups (4 waves) and many slices: the pre-pass runs with cold
     // thresholds, where the waves of a workgroup queue on its admission lock
     int64_t ss = std::min<int64_t>(1024, std::max<int64_t>(8, sample / 8192));
@@ -241,6 +240,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   const int nslots = std::max(pl.n_slices, pl.seed_slices);
   HIP_TRY(ix->w_part_d.ensure((size_t)chunk * nslots * k * sizeof(float)));
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
+  HIP_TRY(ix->w_part_cnt.ensure((size_t)chunk * nslots * sizeof(int)));
   HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
   {
     const size_t ms = vaq::merge_scratch_elems(nslots, chunk, k);
@@ -291,6 +291,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.qb = pl.qb;
     sp.part_d = ix->w_part_d.as<float>();
     sp.part_id = ix->w_part_id.as<int>();
+    sp.part_cnt = ix->w_part_cnt.as<int>();
     sp.final_labels = nullptr;
     sp.final_dist = nullptr;
     sp.id_base = ix->id_base;
@@ -305,7 +306,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       sp.nwaves = 4;
       HIP_TRY(vaq::launch_scan(sp, nullptr, st));
       sp.nwaves = pl.nwaves;
-      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, pl.seed_slices, k, (int64_t)pl.seed_slices * k, n,
+      // (the pre-pass ran cold: its lists are full, so the plain 16-way tree, not the compacting level)
+      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, nullptr, pl.seed_slices, k, (int64_t)pl.seed_slices * k, n,
                                 k, 0, 0, nullptr, nullptr, ix->w_thr.as<unsigned>(),
                                 ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
     }
@@ -326,7 +328,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
     const int lists = ix->N > 0 ? pl.n_slices : 0;
     if (!direct)
-      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, lists, k, (int64_t)pl.n_slices * k, n, k,
+      // after a seeded scan most lists are empty: let the first merge level gather by the counts
+      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, pl.seed_slices > 0 ? sp.part_cnt : nullptr, lists, k,
+                                (int64_t)pl.n_slices * k, n, k,
                                 ix->id_base, 0, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k,
                                 nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
     if (timing) HIP_TRY(hipEventRecord(ev[5], st));
@@ -465,7 +469,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
     for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
                       &ix->d_bstart, &ix->w_q,
-                      &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_labels,
+                      &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_part_cnt, &ix->w_labels,
                       &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id})
       b->release();
   }
@@ -671,7 +675,7 @@ int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", device_id);
   if (n_lists > 16) return fail(VAQHIP_EUNSUPPORTED, "at most 16 lists per merge");
   if (list_stride < 0 || query_stride < 0) return fail(VAQHIP_EINVAL, "negative stride");
-  HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, n_lists, list_stride, query_stride, nq, k, 0, 1,
+  HIP_TRY(vaq::launch_merge(d_dist_lists, d_label_lists, nullptr, n_lists, list_stride, query_stride, nq, k, 0, 1,
                             d_labels_out, d_dist_out, nullptr, nullptr, nullptr,
                             static_cast<hipStream_t>(stream)));
   return VAQHIP_OK;
@@ -824,6 +828,9 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "early_abandon") {
     if (value < 0 || value > 3) return fail(VAQHIP_EINVAL, "early_abandon must be 0..3");
     ix->opt_ea = (int)value;
+  } else if (k == "seed_fraction") {
+    if (value < 2 || value > 65536) return fail(VAQHIP_EINVAL, "seed_fraction must be 2..65536");
+    ix->opt_seed_frac = (int)value;
   } else if (k == "hot_buckets") {
     if (value < 0 || value > 32) return fail(VAQHIP_EINVAL, "hot_buckets must be 0..32");
     ix->opt_hot = (int)value;
