@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--ea", type=int, default=3, help="early abandon: 0 off, 1 queue, 2 in place, 3 auto")
     ap.add_argument("--nwaves", type=int, default=0, help="wavefronts per scan workgroup (0 = auto)")
     ap.add_argument("--seed", type=int, default=1, help="threshold-seeding pre-pass on/off")
+    ap.add_argument("--order", type=int, default=0, help="best-first slice order on/off (experimental)")
     ap.add_argument("--seed-frac", type=int, default=0, help="pre-pass scans N / this many rows (0 = default 64)")
     ap.add_argument("--hot", type=int, default=-1, help="best-first buckets per workgroup (0..32, -1 = default)")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
@@ -185,6 +186,7 @@ def main():
     if args.nwaves:
         v.set_option("waves_per_workgroup", args.nwaves)
     v.set_option("seed_thresholds", args.seed)
+    v.set_option("ordered_slices", args.order)
     if args.seed_frac:
         v.set_option("seed_fraction", args.seed_frac)
     if args.hot >= 0:

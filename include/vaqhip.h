@@ -192,6 +192,10 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       workgroup scans best-first, closest first term first, before
  *                       the rest of its slice; 0 = natural order only
  *   "waves_per_workgroup" 0 = auto (most wavefronts per CU), else 4, 8 or 16
+ *   "ordered_slices"    0 (default): slices in row order.  1: when a query's rows are
+ *                       split over 2..4096 workgroups, dispatch the slices
+ *                       best-first per query batch instead of running the sampling
+ *                       pre-pass (experimental; measured slower)
  *   "seed_thresholds"   1 (default): when a query's rows are split over several
  *                       workgroups, a pre-pass over 1/64 of the rows seeds their
  *                       admission thresholds; 0: every workgroup warms up alone

@@ -263,9 +263,12 @@ def test_seeded_multislice(vaqlib, oracle, bits):
     o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=3)
     ad = oracle_all_dists(oracle, c, Xp)
     seen = []
-    for seed, slices, qb, ea in [(1, 300, 2, 1), (0, 300, 2, 1), (1, 0, 1, 3), (1, 1, 2, 3), (1, 257, 4, 2), (1, 300, 2, 2)]:
+    for seed, slices, qb, ea, order in [(1, 300, 2, 1, 0), (0, 300, 2, 1, 0), (1, 0, 1, 3, 0), (1, 1, 2, 3, 0),
+                                        (1, 257, 4, 2, 0), (1, 300, 2, 2, 0), (1, 300, 2, 1, 1), (1, 0, 1, 3, 1),
+                                        (0, 2035, 2, 2, 1), (1, 77, 4, 1, 1)]:
         v.set_option("seed_thresholds", seed)
         v.set_option("early_abandon", ea)
+        v.set_option("ordered_slices", order)
         v.set_option("slices", slices)
         v.set_option("queries_per_pass", qb)
         v.set_option("timing", 1)
@@ -273,7 +276,7 @@ def test_seeded_multislice(vaqlib, oracle, bits):
         t = v.last_timing()
         seen.append((seed, slices, t["slices"], t["seed_slices"]))
         assert_topk_matches(a.labels.reshape(3, k), a.distances.reshape(3, k), o_lab, o_dis, ad,
-                            what=f"seed={seed} slices={slices} qb={qb}")
+                            what=f"seed={seed} slices={slices} qb={qb} ea={ea} order={order}")
     assert seen[0][2] > 1 and seen[0][3] > 0, seen     # auto plan: multi-slice and seeded
     assert seen[1][3] == 0 and seen[3][3] == 0, seen   # seeding off / single slice
 

@@ -66,6 +66,7 @@ struct ScanParams {
   int64_t slice_stride;   // rows between slice starts (== slice_rows for a full scan,
                           // larger for the sampling pre-pass)
   int share_thr;          // 1: exchange thresholds between workgroups through g_thr
+  const int *slice_order; // [query batches][n_slices] best-first slice order, or nullptr = row order
   int seq;                // 1: sequential row sum (BitVecEngine::queryLUT) instead of groups of 4
   int32_t *final_labels;  // non-null (needs n_slices == 1): results written directly, [nq][k]
   float *final_dist;
@@ -102,6 +103,10 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 // occurs, -1 otherwise; the caller back-fills).  Synchronises the stream.
 hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift,
                               uint32_t *d_perm, int *d_bucket_start, hipStream_t st);
+// Best-first slice order per query batch (n_slices <= 4096, n_buckets <= 4096)
+hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, const int *bstart,
+                              int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,
+                              int64_t n_rows, int *order, hipStream_t st);
 // LDS geometry of a scan workgroup for top-k = k
 void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap);
 // bytes of LDS a scan workgroup of `nwaves` wavefronts needs

@@ -762,7 +762,8 @@ template <int QB> struct ScanCtx {
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       unsigned t = __hip_atomic_load(&sel[q].hdr[SEL_THR_D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (multi_slice && wave == 0 && (st & (THR_GLOBAL_EVERY - 1)) == 0) {
+      // (every 8 steps while the scan is young: that is when other workgroups' thresholds move most)
+      if (multi_slice && wave == 0 && ((st & (THR_GLOBAL_EVERY - 1)) == 0 || st < THR_GLOBAL_EVERY)) {
         const unsigned g = __hip_atomic_load(&g_thr[qi[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (g < t) {
           sel_lock(sel[q], lane);
@@ -937,8 +938,10 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
   if (v >= total) return;
-  const int slice = v / nqb;
-  const int qbatch = v - slice * nqb;
+  const int vslice = v / nqb;
+  const int qbatch = v - vslice * nqb;
+  // best-first: the vslice-th most promising slice of this batch (or the vslice-th in row order)
+  const int slice = p.slice_order ? p.slice_order[(size_t)qbatch * p.n_slices + vslice] : vslice;
 
   // slice = [r0, r0 + slice_rows); slice_rows is a multiple of the largest
   // workgroup step and the code buffer is padded to a multiple of it, so every
@@ -1184,8 +1187,10 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   const int total = nqb * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
   if (v >= total) return;
-  const int slice = v / nqb;
-  const int qbatch = v - slice * nqb;
+  const int vslice = v / nqb;
+  const int qbatch = v - vslice * nqb;
+  // best-first: the vslice-th most promising slice of this batch (or the vslice-th in row order)
+  const int slice = p.slice_order ? p.slice_order[(size_t)qbatch * p.n_slices + vslice] : vslice;
 
   const int r0 = (int)((int64_t)slice * p.slice_stride);
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
@@ -1415,6 +1420,85 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   }
   if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);
   cx.write_out(p, slice, qbatch);
+}
+
+// ---------------------------------------------------------------------------
+// Best-first order of the row slices of a multi-slice scan, one list per query
+// batch: slices are ranked by the smallest first LUT term (or its per-bucket
+// lower bound) that any query of the batch sees in any bucket the slice touches.
+// Workgroups are dispatched in blockIdx order, so with this table the first
+// ones scan the most promising rows, publish tight thresholds, and the rest
+// skip their buckets unread -- it replaces the sampling pre-pass.
+// grid = query batches; n_slices <= SLICE_ORDER_MAX (packed-key sort in LDS).
+// ---------------------------------------------------------------------------
+constexpr int SLICE_ORDER_MAX = 4096;
+
+__global__ __launch_bounds__(256) void slice_order_kernel(
+    const float *__restrict__ lut, int lut_floats, int nq, int qb, const int *__restrict__ bstart,
+    int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices, int64_t n_rows,
+    int *__restrict__ order) {
+  __shared__ unsigned key[SLICE_ORDER_MAX];
+  __shared__ float lbk[HOT_MAX_BUCKETS];
+  const int batch = blockIdx.x, tid = threadIdx.x;
+  // per-bucket bound over the batch's queries
+  for (int b = tid; b < n_buckets; b += 256) {
+    float m = INFINITY;
+    for (int q = 0; q < qb; q++) {
+      int x = batch * qb + q;
+      if (x >= nq) x = nq - 1;
+      for (int c = b << bucket_shift; c < ((b + 1) << bucket_shift); c++) {
+        const float v = lut[(size_t)x * lut_floats + c];
+        m = v < m ? v : m;
+      }
+    }
+    lbk[b] = m;
+  }
+  __syncthreads();
+  int P = 2;
+  while (P < n_slices) P <<= 1;
+  const unsigned idx_mask = (unsigned)P - 1u;
+  for (int s = tid; s < P; s += 256) {
+    unsigned k = 0xffffffffu;
+    if (s < n_slices) {
+      const int64_t r0 = (int64_t)s * slice_rows;
+      int64_t r1 = r0 + slice_rows;
+      if (r1 > n_rows) r1 = n_rows;
+      int lo = 0, hi = n_buckets;  // bucket of r0
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bstart[mid] <= r0) lo = mid; else hi = mid;
+      }
+      float m = INFINITY;
+      for (int b = lo; b < n_buckets && bstart[b] < r1; b++)
+        if (bstart[b + 1] > r0 && lbk[b] < m) m = lbk[b];
+      k = m == m ? ((__builtin_bit_cast(unsigned, m) & ~idx_mask) | (unsigned)s) : (0xffffffffu & ~idx_mask) | (unsigned)s;
+    }
+    key[s] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += 256) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const unsigned a = key[i], c = key[j];
+        if ((a > c) == ((i & size) == 0)) { key[i] = c; key[j] = a; }
+      }
+      __syncthreads();
+    }
+  // padding keys (0xffffffff) sort last; real ones carry their slice index in the low bits
+  for (int r = tid; r < n_slices; r += 256) order[(size_t)batch * n_slices + r] = (int)(key[r] & idx_mask);
+}
+
+hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, const int *bstart,
+                              int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,
+                              int64_t n_rows, int *order, hipStream_t st) {
+  if (n_slices > SLICE_ORDER_MAX || n_buckets > HOT_MAX_BUCKETS) return hipErrorInvalidValue;
+  const int nqb = (nq + qb - 1) / qb;
+  if (nqb == 0) return hipSuccess;
+  hipLaunchKernelGGL(slice_order_kernel, dim3(nqb), dim3(256), 0, st, lut, lut_floats, nq, qb, bstart,
+                     n_buckets, bucket_shift, slice_rows, n_slices, n_rows, order);
+  return hipGetLastError();
 }
 
 // __global__ entry points: the SGPR-capped one for EA_NONE / EA_QUEUE, a plain one for EA_INPLACE

@@ -81,10 +81,10 @@ struct vaqhip_index {
   int bucket_shift = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
   // workspace (grow-only, reused across searches)
-  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id;
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -114,6 +114,7 @@ struct Plan {
   // sampling pre-pass that seeds the shared thresholds (0 slices = none)
   int seed_slices;
   int64_t seed_rows, seed_stride;
+  bool ordered;  // slices dispatched best-first per query batch
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -186,7 +187,11 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   // bound of the final k-th, so results are unchanged.
   pl->seed_slices = 0;
   pl->seed_rows = pl->seed_stride = 0;
-  if (ea && ix->opt_seed && s >= SEED_MIN_SLICES && N >= SEED_MIN_ROWS) {
+  // best-first slice order (slice_order_kernel): an alternative to the pre-pass, off by default --
+  // measured slower (250M rows, 2 queries: 1.21 vs 0.70 ms; 32 queries: 8.7 vs 5.6 ms): the first
+  // wave of workgroups all starts cold, and batches no longer share a slice's rows through L2
+  pl->ordered = ea && ix->opt_order && s > 1 && s <= 4096 && ix->n_buckets <= 4096;
+  if (ea && ix->opt_seed && !pl->ordered && s >= SEED_MIN_SLICES && N >= SEED_MIN_ROWS) {
     const int64_t sample = std::max<int64_t>(N / ix->opt_seed_frac, (int64_t)16 * k);
     // small workgroups (4 waves) and many slices: the pre-pass runs with cold
     // thresholds, where the waves of a workgroup queue on its admission lock
@@ -294,6 +299,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.part_cnt = ix->w_part_cnt.as<int>();
     sp.final_labels = nullptr;
     sp.final_dist = nullptr;
+    sp.slice_order = nullptr;
     sp.id_base = ix->id_base;
     int grid = 0;
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
@@ -316,6 +322,14 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.slice_rows = pl.slice_rows;
     sp.slice_stride = pl.slice_rows;
     sp.share_thr = pl.n_slices > 1;
+    if (pl.ordered && ix->N > 0) {
+      const int nqb = (n + pl.qb - 1) / pl.qb;
+      HIP_TRY(ix->w_order.ensure((size_t)nqb * pl.n_slices * sizeof(int)));
+      HIP_TRY(vaq::launch_slice_order(ix->w_lut.as<float>(), ix->lut_floats, n, pl.qb, ix->d_bstart.as<int>(),
+                                      ix->n_buckets, ix->bucket_shift, pl.slice_rows, pl.n_slices, ix->N,
+                                      ix->w_order.as<int>(), st));
+      sp.slice_order = ix->w_order.as<int>();
+    }
     const bool direct = pl.n_slices == 1 && ix->N > 0;  // the single list per query is the result
     if (direct) {
       sp.final_labels = d_labels + (size_t)q0 * k;
@@ -329,7 +343,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     const int lists = ix->N > 0 ? pl.n_slices : 0;
     if (!direct)
       // after a seeded scan most lists are empty: let the first merge level gather by the counts
-      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, pl.seed_slices > 0 ? sp.part_cnt : nullptr, lists, k,
+      HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, (pl.seed_slices > 0 || pl.ordered) ? sp.part_cnt : nullptr,
+                                lists, k,
                                 (int64_t)pl.n_slices * k, n, k,
                                 ix->id_base, 0, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k,
                                 nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
@@ -470,7 +485,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
     for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
                       &ix->d_bstart, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_part_cnt, &ix->w_labels,
-                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id})
+                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id, &ix->w_order})
       b->release();
   }
   delete ix;
@@ -828,6 +843,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "early_abandon") {
     if (value < 0 || value > 3) return fail(VAQHIP_EINVAL, "early_abandon must be 0..3");
     ix->opt_ea = (int)value;
+  } else if (k == "ordered_slices") {
+    ix->opt_order = value != 0;
   } else if (k == "seed_fraction") {
     if (value < 2 || value > 65536) return fail(VAQHIP_EINVAL, "seed_fraction must be 2..65536");
     ix->opt_seed_frac = (int)value;
