@@ -401,3 +401,33 @@ def test_query_lut_sequential(vaqlib, oracle, ndim, seed):
         a = v.search(X, k)
         assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
                             what=f"queryLUT ndim={ndim} qb={qb} ea={ea}")
+
+
+def test_lock_contention_stress(vaqlib, oracle):
+    """Worst case for the workgroup admission lock: every row has the same code, so every
+    row ties with the threshold distance and only the label order decides; 16 waves per
+    workgroup, several slices, repeated runs must all return rows 0..k-1."""
+    c = make_case(901, 128, [8] * 16, 400_000, 5)
+    c["codes"][:] = c["codes"][7]
+    v = make_index(c)
+    v.set_option("waves_per_workgroup", 16)
+    k = 100
+    want = np.tile(np.arange(k, dtype=np.int32), (5, 1))
+    for it, (qb, ea, sl, hot) in enumerate([(2, 1, 0, 16), (2, 1, 7, 16), (4, 1, 3, 0), (1, 2, 5, 16), (2, 0, 2, 16)] * 3):
+        v.set_option("queries_per_pass", qb)
+        v.set_option("early_abandon", ea)
+        v.set_option("slices", sl)
+        v.set_option("hot_buckets", hot)
+        a = v.search(c["X"], k)
+        assert np.array_equal(a.labels.reshape(5, k), want), (it, qb, ea, sl, hot)
+    # and a tie-heavy but not degenerate case: 3-bit codes, 4096 distinct rows at most
+    c2 = make_case(902, 16, [3] * 4, 200_000, 8, integer=True)
+    v2 = make_index(c2)
+    v2.set_option("waves_per_workgroup", 16)
+    Xp = oracle.project(c2["X"], c2["eig"])
+    o_lab, o_dis = oracle.search(Xp, c2["cents"], c2["codes"], k, max_bits=3, projected=True, nthreads=4)
+    ad = oracle_all_dists(oracle, c2, Xp)
+    for rep in range(4):
+        v2.set_option("slices", [0, 3, 11, 1][rep])
+        a = v2.search(c2["X"], k)
+        assert_topk_matches(a.labels.reshape(8, k), a.distances.reshape(8, k), o_lab, o_dis, ad, what=f"ties rep {rep}")
