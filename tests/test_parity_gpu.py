@@ -78,6 +78,11 @@ CONFIGS = [
     (109, 128, [8] * 8, 70000, 2, 1000, {}),           # k near the build's maximum
     (110, 128, [8] * 8, 20000, 33, 10, {"rotate": False}),
     (111, 32, [15, 1, 8, 8], 6000, 3, 20, {}),
+    # the reference's default method string allows up to 13 bits in 32 subspaces: the lookup
+    # tables (31488 floats; 126 KB per query) no longer fit LDS for 2+ queries per pass, so the
+    # tail tables are read from global memory
+    (112, 64, [13, 13, 12, 12, 11, 10] + [8] * 8 + [7] * 10 + [6] * 8, 8000, 4, 100, {}),
+    (113, 48, [14, 14, 13, 13] + [6] * 8, 5000, 3, 64, {}),
 ]
 
 

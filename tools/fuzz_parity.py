@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on a GPU box: random index shapes, bit allocations, sizes,
+k, and scan options, each checked against the CPU oracle under the tie contract.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import vaq_amd
+from helpers import assert_topk_matches, make_case
+from oracle import pyoracle as po
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+po.build(ref=False)
+t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0
+while time.time() - t0 < budget:
+    M = int(rng.choice([4, 8, 8, 12, 16, 16, 20, 32, 64]))
+    L = int(rng.choice([1, 2, 4, 8, 16]))
+    D = M * L
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        bits = [8] * M
+    elif kind == 1:
+        bits = [int(rng.integers(1, 9)) for _ in range(M)]
+    elif kind == 2:
+        bits = sorted([int(rng.integers(1, 13)) for _ in range(M)], reverse=True)
+    else:
+        bits = [int(rng.integers(3, 6))] * M
+    while sum(bits) > 256:
+        bits[int(np.argmax(bits))] -= 1
+    N = int(rng.choice([1, 63, 64, 65, 500, 4097, 20000, 150000]))
+    nq = int(rng.choice([1, 2, 3, 7, 33]))
+    k = int(rng.choice([1, 5, 64, 100, 128, 129, 500]))
+    c = make_case(int(rng.integers(1 << 30)), D, bits, N, nq, dup_frac=float(rng.choice([0, 0.05, 0.5])),
+                  integer=bool(rng.integers(0, 4) == 0), rotate=bool(rng.integers(0, 2)))
+    v = vaq_amd.VaqHip()
+    v.mBitsAlloc = bits; v.mCentroidsPerSubs = c["cents"]; v.mEigenVectors = c["eig"]; v.mCodebook = c["codes"]
+    Xp = po.project(c["X"], c["eig"]) if c["eig"] is not None else c["X"]
+    o_lab, o_dis = po.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
+    ad = np.stack([po.all_dists(po.create_lut(Xp[q], c["cents"], max(bits)), c["codes"]) for q in range(nq)])
+    for _ in range(4):
+        opts = dict(queries_per_pass=int(rng.choice([0, 1, 2, 4])), early_abandon=int(rng.integers(0, 4)),
+                    slices=int(rng.choice([0, 0, 1, 2, 5, 300])), hot_buckets=int(rng.choice([0, 3, 16, 32])),
+                    waves_per_workgroup=int(rng.choice([0, 4, 8, 16])), seed_thresholds=int(rng.integers(0, 2)),
+                    ordered_slices=int(rng.integers(0, 2)))
+        for key, val in opts.items():
+            v.set_option(key, val)
+        try:
+            a = v.search(c["X"], k)
+        except vaq_amd.VaqHipError as e:
+            if e.code == -2:  # outside this build's limits (reported, not a parity failure)
+                n_unsupported = globals().get("n_unsupported", 0) + 1
+                globals()["n_unsupported"] = n_unsupported
+                break
+            raise
+        try:
+            ties += assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
+                                        what=f"M={M} L={L} bits={bits} N={N} nq={nq} k={k} {opts}")
+        except AssertionError as e:
+            print("MISMATCH", e); print("case seed info:", M, L, bits, N, nq, k, opts); sys.exit(1)
+        n_searches += 1
+    v.close(); n_cases += 1
+print("unsupported (EUNSUPPORTED) cases:", globals().get("n_unsupported", 0))
+print(f"fuzz ok: {n_cases} indexes, {n_searches} searches, {ties} boundary-tie queries, {time.time()-t0:.0f}s, seed {seed}")

@@ -52,6 +52,8 @@ struct ScanParams {
   const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
   const float *lut;       // [nq][lut_floats]
   int lut_floats;
+  int lds_subs;           // tables of subspaces [0, lds_subs) are staged in LDS ...
+  int lut_lds_entries;    // ... = this many packed LUT entries; the rest is read from `lut`
   int nq;
   int k;
   int kp;                 // power of two >= k: slots of a workgroup's best list (per query)

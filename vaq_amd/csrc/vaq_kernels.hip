@@ -1177,7 +1177,7 @@ template <int W> struct BitsItem {
   }
 };
 
-template <int W, int QB, int EA>
+template <int W, int QB, int EA, bool TAIL>
 __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
@@ -1197,10 +1197,10 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
 
   ScanCtx<QB> cx;
-  cx.setup(smem, p, p.lut_floats, qbatch, tid, nthreads);
+  cx.setup(smem, p, p.lut_lds_entries, qbatch, tid, nthreads);
   if (EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
-  cx.stage_lut(p, p.lut_floats, tid, nthreads);
+  cx.stage_lut(p, p.lut_lds_entries, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
   __syncthreads();
@@ -1218,6 +1218,18 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   //   sequential (BitVecEngine::queryLUT, BitVecEngine.hpp:1296-1300): dist += l_s
   //     (dism mirrors dist so the survivor tests read the same variable in both modes)
   const bool seq = p.seq != 0;
+  // table s is staged in LDS when s < lds_subs; larger allocations (e.g. 32 subspaces of up
+  // to 13 bits) keep their tail tables in global memory -- only early-abandon survivors ever
+  // reach those, and they sit in L2
+  const int lds_subs = p.lds_subs;
+  // (TAIL = false: every table is resident and this is a plain LDS read)
+  auto lookup = [&](const SubDesc &sd, const int s, const uint32_t c) -> LT {
+    if (!TAIL || s < lds_subs) return lut[sd.lut_off + c];
+    LT v;
+#pragma unroll
+    for (int q = 0; q < QB; q++) lv_set<QB>(v, q, p.lut[(size_t)cx.qi[q] * p.lut_floats + sd.lut_off + c]);
+    return v;
+  };
   auto chain = [&](const int s, const LT l, float (&acc)[QB], float (&dism)[QB]) {
     const int ph = s & 3;
 #pragma unroll
@@ -1261,7 +1273,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
       if (alive) {
         const uint32_t c =
             __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
-        chain(s, lut[sd.lut_off + c], acc, dism);
+        chain(s, lookup(sd, s, c), acc, dism);
         if (seq || (s & 3) == 3) alive = cx.survives(acc);
       }
     }
@@ -1284,7 +1296,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
         if (!ea || alive) {
           const uint32_t c =
               __builtin_amdgcn_alignbit(hi, lo, (unsigned)sd.shift) & (unsigned)(sd.ncent - 1);
-          chain(s, lut[sd.lut_off + c], acc, dism);
+          chain(s, lookup(sd, s, c), acc, dism);
           if (ea && (seq || (s & 3) == 3)) alive = cx.survives(acc);
         }
       }
@@ -1393,7 +1405,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
                 chain(0, lut[w0w & (unsigned)(s0c.ncent - 1)], acc, dism);
               // A: dism += l1 (field 1 lies inside dword 0)
               if (M > 1)
-                chain(1, lut[s1.lut_off + ((w0w >> s1.shift) & (unsigned)(s1.ncent - 1))], acc, dism);
+                chain(1, lookup(s1, 1, (w0w >> s1.shift) & (unsigned)(s1.ncent - 1)), acc, dism);
               bool live = (row >= pos) && (row < be) && cx.survives(dism);
               if (live && M > 2) {
                 // A2: fields 2 and 3 (dwords 0..1) complete the first group
@@ -1401,8 +1413,8 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
                                                   : (w1w >> s2.shift)) & (unsigned)(s2.ncent - 1);
                 const uint32_t c3 = (s3.word == 0 ? __builtin_amdgcn_alignbit(w1w, w0w, (unsigned)s3.shift)
                                                   : (w1w >> s3.shift)) & (unsigned)(s3.ncent - 1);
-                chain(2, lut[s2.lut_off + c2], acc, dism);
-                if (M > 3) chain(3, lut[s3.lut_off + c3], acc, dism);
+                chain(2, lookup(s2, 2, c2), acc, dism);
+                if (M > 3) chain(3, lookup(s3, 3, c3), acc, dism);
                 live = cx.survives(seq ? acc : (M > 3 ? acc : dism));
               }
               if (EA == EA_QUEUE) {
@@ -1512,11 +1524,16 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_inplace_kernel(Sc
 }
 template <int W, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bits_kernel(ScanParams p) {
-  scan_bits_body<W, QB, EA>(p);
+  scan_bits_body<W, QB, EA, false>(p);
 }
 template <int W, int QB>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_inplace_kernel(ScanParams p) {
-  scan_bits_body<W, QB, EA_INPLACE>(p);
+  scan_bits_body<W, QB, EA_INPLACE, false>(p);
+}
+// tail LUT tables in global memory (big allocations); one form per early-abandon mode
+template <int W, int QB, int EA>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_tail_kernel(ScanParams p) {
+  scan_bits_body<W, QB, EA, true>(p);
 }
 
 // ---- launch geometry shared with the host --------------------------------
@@ -1533,6 +1550,7 @@ void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qc
   *qcap = ea == EA_QUEUE ? 64 + 64 * rows_per_item(layout, M) : 0;
 }
 
+// lut_floats: LUT entries staged in LDS (all of them, or the resident prefix of the bit-packed path)
 size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves,
                       int n_buckets, int bucket_shift) {
   int kp, ccap, qcap;
@@ -1569,19 +1587,46 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
   default: return hipErrorInvalidValue;                                                   \
   }
 
+#define VAQ_DISPATCH_TAIL_EA(A, Q)                                                          \
+  switch (p.ea) {                                                                         \
+  case EA_NONE: return launch_scan_kernel(scan_bits_tail_kernel<A, Q, EA_NONE>, p, lds, grid, st);       \
+  case EA_QUEUE: return launch_scan_kernel(scan_bits_tail_kernel<A, Q, EA_QUEUE>, p, lds, grid, st);     \
+  case EA_INPLACE: return launch_scan_kernel(scan_bits_tail_kernel<A, Q, EA_INPLACE>, p, lds, grid, st); \
+  default: return hipErrorInvalidValue;                                                   \
+  }
+#define VAQ_DISPATCH_TAIL(A)                                                              \
+  switch (p.qb) {                                                                         \
+  case 1: VAQ_DISPATCH_TAIL_EA(A, 1)                                                      \
+  case 2: VAQ_DISPATCH_TAIL_EA(A, 2)                                                      \
+  default: return hipErrorInvalidValue; /* the host plans Qb <= 2 when tables spill */    \
+  }
+
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const int nqb = (p.nq + p.qb - 1) / p.qb;
   const int total = nqb * p.n_slices;
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
-  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_floats, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
+  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
                                    p.bucket_shift);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes, 8)
     case 16: VAQ_DISPATCH_QB(scan_bytes, 16)
     case 32: VAQ_DISPATCH_QB(scan_bytes, 32)
+    default: return hipErrorInvalidValue;
+    }
+  }
+  if (p.lds_subs < p.M) {  // some tables stay in global memory
+    switch (p.W) {
+    case 1: VAQ_DISPATCH_TAIL(1)
+    case 2: VAQ_DISPATCH_TAIL(2)
+    case 3: VAQ_DISPATCH_TAIL(3)
+    case 4: VAQ_DISPATCH_TAIL(4)
+    case 5: VAQ_DISPATCH_TAIL(5)
+    case 6: VAQ_DISPATCH_TAIL(6)
+    case 7: VAQ_DISPATCH_TAIL(7)
+    case 8: VAQ_DISPATCH_TAIL(8)
     default: return hipErrorInvalidValue;
     }
   }

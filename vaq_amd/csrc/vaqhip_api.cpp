@@ -109,6 +109,7 @@ struct DeviceGuard {
 
 struct Plan {
   int qb, ea, kp, ccap, qcap, nwaves, n_slices;
+  int lds_subs, lut_lds_entries;  // LUT tables staged in LDS (a prefix of the subspaces)
   int64_t slice_rows;
   size_t lds;
   // sampling pre-pass that seeds the shared thresholds (0 slices = none)
@@ -139,28 +140,42 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   // holds 160 KB of LDS and 32 waves (the scan kernels stay within 64 VGPRs
   // for Qb <= 2; Qb = 4 needs about twice that, i.e. half the waves).
   const int wave_cap = qb <= 2 ? 32 : 24;
-  int best_nw = 0, best_waves = 0;
+  // LUT tables are staged in LDS for a prefix of the subspaces (all of them whenever they
+  // fit; the byte-code kernels need all).  The bit-packed kernel reads the tail tables from
+  // global memory, so big allocations (32 x up to 13 bits) still run; only table 0
+  // (bucket bounds) must be resident.
+  const int need = ix->layout == vaq::LAYOUT_BYTES ? ix->M : 1;
+  int best_nw = 0, best_waves = 0, subs = ix->M, entries = ix->lut_floats;
   for (;;) {
-    for (int nw : {4, 8, 16}) {
-      if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
-      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, nw, ix->n_buckets,
-                                                  ix->bucket_shift);
-      if (lds > LDS_LIMIT) continue;
-      const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
-      if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
+    for (subs = ix->M; subs >= need; subs--) {
+      entries = subs == ix->M ? ix->lut_floats : ix->sub[subs].lut_off;
+      best_nw = 0;
+      best_waves = 0;
+      for (int nw : {4, 8, 16}) {
+        if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
+        const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, nw, ix->n_buckets,
+                                               ix->bucket_shift);
+        if (lds > LDS_LIMIT) continue;
+        const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
+        if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
+      }
+      if (best_nw) break;
     }
+    if (best_nw && subs < ix->M && qb > 2) best_nw = 0;  // spilled tables: kernels exist for Qb <= 2 only
     if (best_nw) break;
     if (qb > 1) qb >>= 1;
     else
       return fail(VAQHIP_EUNSUPPORTED,
-                  "lookup tables of %d floats plus top-%d buffers do not fit %zu B of LDS",
-                  ix->lut_floats, k, LDS_LIMIT);
+                  "the lookup tables of the first %d subspaces plus top-%d buffers do not fit %zu B of LDS",
+                  need, k, LDS_LIMIT);
   }
+  pl->lds_subs = subs;
+  pl->lut_lds_entries = entries;
   pl->qb = qb;
   pl->ea = ea;
   pl->nwaves = best_nw;
   vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
-  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, ix->lut_floats, qb, k, ea, best_nw, ix->n_buckets,
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, best_nw, ix->n_buckets,
                                 ix->bucket_shift);
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const int64_t N = ix->N;
@@ -284,6 +299,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.n_hot = 0;
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
+    sp.lds_subs = pl.lds_subs;
+    sp.lut_lds_entries = pl.lut_lds_entries;
     sp.nq = n;
     sp.k = k;
     sp.kp = pl.kp;
