@@ -46,16 +46,19 @@ extern "C" {
 #define VAQHIP_ESTATE       -7   /* call order (e.g. search before codes were added)            */
 
 /* search method bits, numerically equal to VAQ::NNMethod (VAQ.hpp:38-49).
- * Only HEAP and EA are on this path; both run the same kernel because the
- * reference's early abandon returns results identical to HEAP
- * (VAQ.cpp:1694-1727 vs 1729-1758). */
+ * HEAP and EA run the same kernels because the reference's early abandon
+ * returns results identical to HEAP (VAQ.cpp:1694-1727 vs 1729-1758).  TI is
+ * the triangle-inequality cluster pruning (VAQ.cpp:799-826, 1540-1692); see
+ * vaqhip_index_set_ti_clusters. */
 #define VAQHIP_METHOD_EA   0x02u
+#define VAQHIP_METHOD_TI   0x04u
 #define VAQHIP_METHOD_HEAP 0x80u
 
 /* limits of this build */
 #define VAQHIP_MAX_SUBSPACES 128
 #define VAQHIP_MAX_BITS      15    /* VAQ.cpp:787-798 dispatches CreateLUT<9..15> */
 #define VAQHIP_MAX_K         1024
+#define VAQHIP_MAX_TI_CLUSTERS 4096 /* mTIClusterNum; the paper's runs use 100..2000 */
 
 typedef struct vaqhip_index vaqhip_index;
 
@@ -101,6 +104,32 @@ int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor,
                                int64_t N, int64_t id_base);
 int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
                                       int64_t N, int64_t id_base, void *stream);
+
+/* VAQ::clusterTI (VAQ.hpp:106, VAQ.cpp:878-999) from the point where mTIClusters
+ * exists: `clusters` is mTIClusters, T x (seg_num * D/M) row-major, i.e. T
+ * centres over the first seg_num subspaces (mTIClusterNum, mTISegmentNum); how
+ * they were made (the reference: k-means over decoded codes, VAQ.cpp:897-900) is
+ * the caller's business, like the codebooks.  Every code row joins its nearest
+ * centre (VAQ.cpp:926-950), clusters are ordered farthest member first
+ * (:972-979) and the packed codes are regrouped on the GPU (:984-996).  May be
+ * called before or after the codes are set (the reference calls it after
+ * encode); T = 0 returns the index to the exhaustive HEAP/EA form.  Sets /
+ * clears VAQHIP_METHOD_TI in the index's method.  Synchronises.
+ * Labels stay ORIGINAL row indices + id_base, as mTIClustersMember holds them. */
+int vaqhip_index_set_ti_clusters(vaqhip_index *ix, const float *clusters_rowmajor, int T,
+                                 int seg_num);
+
+/* mMethods (VAQ::parseMethodString, VAQ.cpp:1205-1262) and mVisit (VAQ.hpp:84,
+ * demo_vaq --visit-cluster).  With TI:
+ *   - the clusters visited are the first  max(int(T * visit), shortest prefix
+ *     holding k rows)  in ascending query-to-centre distance (VAQ.cpp:1548-1555,
+ *     :1611); visit >= 1 visits all;
+ *   - TI | EA returns the k best of the visited rows; distances are sqrt'ed
+ *     (VAQ.cpp:1583);
+ *   - TI without EA returns the first k rows of the visiting order, as the
+ *     reference does (its bsfKSquared stays 0, VAQ.cpp:1617-1686).
+ * HEAP / EA without TI: the exhaustive scan; `visit` is ignored. */
+int vaqhip_index_set_method(vaqhip_index *ix, unsigned methods, float visit);
 
 /* VAQ::search (VAQ.hpp:102, VAQ.cpp:776-847), HEAP / EA semantics:
  *   queries   nq x D row-major, unprojected (projected by eigvec on the GPU)
@@ -178,6 +207,10 @@ typedef struct {
   int64_t id_base;
   int device_id;
   int layout;          /* 0 = one byte per subspace (all bits == 8), 1 = bit-packed */
+  int ti_clusters;     /* mTIClusterNum, 0 = rows in the exhaustive (bucketed) order */
+  int ti_segments;     /* mTISegmentNum                                     */
+  unsigned methods;    /* VAQHIP_METHOD_* bits in force                     */
+  float visit;         /* mVisit                                            */
 } vaqhip_info;
 int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
 

@@ -289,3 +289,89 @@ def query_lut_1d(qproj, bits, cent_colmajor, codes, k):
                           C.c_int(cm.shape[0]), _up(codes), C.c_int64(codes.shape[0]),
                           C.c_int(codes.shape[1]), C.c_int(k), _ip(ids), _fp(dis))
     return ids, dis
+
+
+class _VoTi(C.Structure):
+    _fields_ = [
+        ("clusters", _f32p), ("T", C.c_int), ("seg", C.c_int), ("visit", C.c_float),
+        ("member", _i32p), ("start", _i32p), ("code2cc", _f32p), ("grouped", _u16p),
+    ]
+
+
+METHOD_TI = 0x04
+
+
+def cluster_ti(codes, cent, clusters, seg, nthreads=1):
+    """VAQ::clusterTI after mTIClusters exists.  Returns dict(member, start,
+    code2cc, grouped)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint16)
+    clusters = np.ascontiguousarray(clusters, dtype=np.float32)
+    N, M = codes.shape
+    L = cent[0].shape[1]
+    T = clusters.shape[0]
+    assert clusters.shape[1] == seg * L
+    arr, keep = _cent_array(cent)
+    member = np.empty(N, dtype=np.int32)
+    start = np.empty(T + 1, dtype=np.int32)
+    code2cc = np.empty(N, dtype=np.float32)
+    grouped = np.empty((N, M), dtype=np.uint16)
+    lib().vo_cluster_ti(_up(codes), C.c_int64(N), C.c_int(M), C.c_int(L), arr, _fp(clusters),
+                        C.c_int(T), C.c_int(seg), C.c_int(nthreads), _ip(member), _ip(start),
+                        _fp(code2cc), _up(grouped))
+    return dict(member=member, start=start, code2cc=code2cc, grouped=grouped,
+                clusters=clusters, seg=seg)
+
+
+def ti_query_order(qproj, clusters):
+    clusters = np.ascontiguousarray(clusters, dtype=np.float32)
+    T, d = clusters.shape
+    qproj = np.ascontiguousarray(qproj, dtype=np.float32)
+    qcc = np.empty(T, dtype=np.float32)
+    order = np.empty(T, dtype=np.int32)
+    lib().vo_ti_query_order(_fp(qproj), _fp(clusters), C.c_int(T), C.c_int(d), _fp(qcc), _ip(order))
+    return qcc, order
+
+
+def search_ti(X, cent, ti, k, visit=1.0, eig=None, max_bits=None, ea=True, nthreads=1,
+              projected=False):
+    """VAQ::search with NNMethod::TI (| EA).  `ti` = cluster_ti(...) output.
+    Returns (labels, distances (sqrt'ed, as the reference stores them), pruned)."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    nq, D = X.shape
+    M = len(cent)
+    L = cent[0].shape[1]
+    ncent = np.array([c.shape[0] for c in cent], dtype=np.int32)
+    if max_bits is None:
+        max_bits = int(np.log2(ncent.max()))
+    arr, keep = _cent_array(cent)
+    ix = _VoIndex()
+    ix.D, ix.M, ix.L, ix.max_bits = D, M, L, max_bits
+    ix.ncent = _ip(ncent)
+    ix.cent = arr
+    if eig is not None:
+        eig = np.ascontiguousarray(eig, dtype=np.float32)
+        ix.eig = _fp(eig)
+    else:
+        ix.eig = None
+    ix.codes = _up(ti["grouped"])
+    ix.N = ti["grouped"].shape[0]
+    t = _VoTi()
+    t.clusters = _fp(ti["clusters"])
+    t.T = ti["clusters"].shape[0]
+    t.seg = ti["seg"]
+    t.visit = visit
+    t.member = _ip(ti["member"])
+    t.start = _ip(ti["start"])
+    t.code2cc = _fp(ti["code2cc"])
+    t.grouped = _up(ti["grouped"])
+    labels = np.empty((nq, k), dtype=np.int32)
+    dists = np.empty((nq, k), dtype=np.float32)
+    pruned = C.c_long(0)
+    method = METHOD_TI | (METHOD_EA if ea else 0)
+    rc = lib().vo_search_ti_all(C.byref(ix), C.byref(t), _fp(X), C.c_int(nq), C.c_int(k),
+                                C.c_uint(method), C.c_int(nthreads),
+                                C.c_int(1 if projected else 0), _ip(labels), _fp(dists),
+                                C.byref(pruned))
+    if rc != 0:
+        raise ValueError(f"vo_search_ti_all failed rc={rc}")
+    return labels, dists, pruned.value

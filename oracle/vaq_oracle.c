@@ -425,6 +425,239 @@ void vo_query_lut_1d(const float *qproj, int ndim, const int *bits,
   free(lut);
 }
 
+/* ------------------------------------------------------------------------
+ * Triangle-inequality cluster pruning.
+ *
+ * VAQ::clusterTI, VAQ.cpp:878-999, from the point where mTIClusters exists
+ * (its k-means, KMeans::staticFitCodebook with srand(time), is training and is
+ * injected like the codebooks):
+ *   :926-950  per code row: x = concatenation of the centroids of its first
+ *             `seg` codes; dists = fvec_L2sqr_ny(x, mTIClusters); the row joins
+ *             the cluster with the smallest sqrt(dist) (strict `<`, first wins);
+ *             mCodeToCCDist[row] = that sqrt
+ *   :972-979  members of a cluster sorted by mCodeToCCDist descending
+ *             (std::sort, order among equal keys is implementation defined;
+ *             restated as: ties by ascending row)
+ *   :984-996  mCodebook regrouped cluster by cluster, mClusterMembersStartIdx
+ * ---------------------------------------------------------------------- */
+typedef struct { float d; int i; } fi_pair;
+static int fi_desc(const void *a, const void *b) {
+  const fi_pair *x = (const fi_pair *)a, *y = (const fi_pair *)b;
+  if (x->d > y->d) return -1;
+  if (x->d < y->d) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+static int fi_asc(const void *a, const void *b) {
+  const fi_pair *x = (const fi_pair *)a, *y = (const fi_pair *)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+
+void vo_cluster_ti(const uint16_t *codes, int64_t N, int M, int L,
+                   const float *const *cent, const float *clusters, int T,
+                   int seg, int nthreads, int *member, int *start,
+                   float *code2cc, uint16_t *grouped) {
+  const int d = seg * L;
+  int *assign = (int *)malloc(sizeof(int) * (size_t)(N > 0 ? N : 1));
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    float *x = (float *)malloc(sizeof(float) * (size_t)d);
+    float *dists = (float *)malloc(sizeof(float) * (size_t)T);
+#ifdef _OPENMP
+#pragma omp for
+#endif
+    for (int64_t i = 0; i < N; i++) {
+      for (int s = 0; s < seg; s++)
+        memcpy(x + (size_t)s * L, cent[s] + (size_t)codes[i * M + s] * L, sizeof(float) * (size_t)L);
+      l2sqr_ny(dists, x, clusters, (size_t)d, (size_t)T);
+      float closest = FLT_MAX;
+      int idx = -1;
+      for (int c = 0; c < T; c++) {
+        float dist = sqrtf(dists[c]);
+        if (dist < closest) { idx = c; closest = dist; }
+      }
+      code2cc[i] = closest;
+      assign[i] = idx;  /* -1 only if every distance is NaN/inf (the reference then indexes [-1]) */
+    }
+    free(x);
+    free(dists);
+  }
+  int *cnt = (int *)calloc((size_t)T + 1, sizeof(int));
+  for (int64_t i = 0; i < N; i++) cnt[(assign[i] < 0 ? 0 : assign[i]) + 1]++;
+  start[0] = 0;
+  for (int c = 0; c < T; c++) start[c + 1] = start[c] + cnt[c + 1];
+  fi_pair *tmp = (fi_pair *)malloc(sizeof(fi_pair) * (size_t)(N > 0 ? N : 1));
+  int *fill = (int *)malloc(sizeof(int) * (size_t)T);
+  for (int c = 0; c < T; c++) fill[c] = start[c];
+  for (int64_t i = 0; i < N; i++) {
+    const int c = assign[i] < 0 ? 0 : assign[i];
+    tmp[fill[c]].d = code2cc[i];
+    tmp[fill[c]].i = (int)i;
+    fill[c]++;
+  }
+  for (int c = 0; c < T; c++)
+    qsort(tmp + start[c], (size_t)(start[c + 1] - start[c]), sizeof(fi_pair), fi_desc);
+  for (int64_t r = 0; r < N; r++) {
+    member[r] = tmp[r].i;
+    if (grouped) memcpy(grouped + r * M, codes + (int64_t)tmp[r].i * M, sizeof(uint16_t) * (size_t)M);
+  }
+  free(fill);
+  free(tmp);
+  free(cnt);
+  free(assign);
+}
+
+/* VAQ::search, TI branch, VAQ.cpp:799-826: qToCCDist = sqrt(fvec_L2sqr_ny(
+ * first seg*L projected dims, mTIClusters)); clusters visited in ascending
+ * qToCCDist (std::sort; ties restated as ascending cluster index). */
+void vo_ti_query_order(const float *qproj, const float *clusters, int T, int d,
+                       float *qcc, int *order) {
+  l2sqr_ny(qcc, qproj, clusters, (size_t)d, (size_t)T);
+  fi_pair *tmp = (fi_pair *)malloc(sizeof(fi_pair) * (size_t)T);
+  for (int c = 0; c < T; c++) {
+    qcc[c] = sqrtf(qcc[c]);
+    tmp[c].d = qcc[c];
+    tmp[c].i = c;
+  }
+  qsort(tmp, (size_t)T, sizeof(fi_pair), fi_asc);
+  for (int c = 0; c < T; c++) order[c] = tmp[c].i;
+  free(tmp);
+}
+
+/* VAQ::searchTriangleInequality, VAQ.cpp:1540-1692, both branches.
+ *   :1548-1551 maxClusterVisit = int(float(T) * mVisit) when mVisit < 1
+ *   :1555      clusters in qToCCIdx order while idx < maxClusterVisit, or
+ *              until k rows have been seen (retrievedEnough, :1611)
+ *   :1564-1568 once k rows are in: the rest of a cluster is pruned when
+ *              bsfK <= qToCCDist[cluster] - mCodeToCCDist[row]
+ *   EA (:1553-1616): the group loop runs while dist < bsfK^2; a row enters when
+ *              dist < bsfK^2; stored distance is sqrt(dist); bsfK = heap top
+ *   no EA (:1617-1686): bsfKSquared stays 0 (it is never updated in the fill
+ *              phase, :1672-1674), so after the first k rows nothing enters:
+ *              the result is the first k rows of the visiting order.  Restated
+ *              as written.
+ * `grouped` is the regrouped mCodebook, `member` = mTIClustersMember
+ * flattened (labels are original rows), code2cc indexed by original row. */
+void vo_search_ti(const float *lut, int ksub, const uint16_t *grouped, int M,
+                  const int *member, const int *start, const float *code2cc,
+                  int T, const float *qcc, const int *order, float visit,
+                  int use_ea, int k, int *ids, float *dis, long *pruned_out) {
+  vo_heap_heapify((size_t)k, dis, ids);
+  float bsfK = 0, bsfKSquared = 0;
+  int counter = 0;
+  long pruned = 0;
+  int maxVisit = T;
+  if (visit < 1) maxVisit = (int)((float)T * visit);
+  int retrievedEnough = 0;
+  for (int ci = 0; (ci < maxVisit) || (!retrievedEnough && ci < T); ci++) {
+    const int c = order[ci];
+    const int s0 = start[c], s1 = start[c + 1];
+    if (s1 == s0) continue;
+    const uint16_t *codes = grouped + (size_t)M * s0;
+    int inter = 0;
+    for (int r = s0; r < s1; r++) {
+      const int dataIndex = member[r];
+      if (counter >= k) {
+        if (bsfK <= (qcc[c] - code2cc[dataIndex])) {
+          pruned += (s1 - s0) - inter;
+          break;
+        }
+        float dist = 0;
+        const float *l = lut;
+        int col;
+        for (col = 0; col < M && (!use_ea || dist < bsfKSquared); col += 4) {
+          float dism;
+          dism  = l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dist += dism;
+        }
+        codes += (M - col);
+        if (dist < bsfKSquared) {
+          dist = sqrtf(dist);
+          vo_heap_pop((size_t)k, dis, ids);
+          vo_heap_push((size_t)k, dis, ids, dist, dataIndex);
+          bsfK = dis[0];
+          bsfKSquared = bsfK * bsfK;
+        }
+      } else {
+        float dist = 0;
+        const float *l = lut;
+        for (int col = 0; col < M; col += 4) {
+          float dism;
+          dism  = l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dism += l[*codes++]; l += ksub;
+          dist += dism;
+        }
+        dist = sqrtf(dist);
+        vo_heap_pop((size_t)k, dis, ids);
+        vo_heap_push((size_t)k, dis, ids, dist, dataIndex);
+        if (dist > bsfK) {
+          bsfK = dist;
+          if (use_ea) bsfKSquared = bsfK * bsfK;  /* :1602 vs :1672-1674 */
+        }
+        counter++;
+      }
+      inter++;
+    }
+    if (counter >= k) retrievedEnough = 1;
+  }
+  for (int i = maxVisit; i < T; i++) pruned += start[order[i] + 1] - start[order[i]];
+  if (pruned_out) *pruned_out = pruned;
+  vo_heap_reorder((size_t)k, dis, ids);
+}
+
+/* VAQ::search with NNMethod::TI set, VAQ.cpp:776-847. */
+int vo_search_ti_all(const vo_index *ix, const vo_ti *ti, const float *X, int nq,
+                     int k, unsigned method, int nthreads, int projected,
+                     int *labels, float *distances, long *total_pruned) {
+  if (ix->M % 4 != 0) return -1;
+  const int D = ix->D, M = ix->M, L = ix->L;
+  const int ksub = 1 << ix->max_bits;
+  float *xp = NULL;
+  const float *Q = X;
+  if (!projected && ix->eig) {
+    xp = (float *)malloc(sizeof(float) * (size_t)nq * D);
+    vo_project(X, nq, D, ix->eig, xp);
+    Q = xp;
+  }
+  if (nthreads < 1) nthreads = 1;
+  long pruned_sum = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads) reduction(+ : pruned_sum)
+#endif
+  {
+    float *lut = (float *)malloc(sizeof(float) * (size_t)ksub * M);
+    float *qcc = (float *)malloc(sizeof(float) * (size_t)ti->T);
+    int *order = (int *)malloc(sizeof(int) * (size_t)ti->T);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (int q = 0; q < nq; q++) {
+      vo_create_lut(Q + (size_t)q * D, M, L, ix->ncent, ix->cent, ksub, lut);
+      vo_ti_query_order(Q + (size_t)q * D, ti->clusters, ti->T, ti->seg * L, qcc, order);
+      long pr = 0;
+      vo_search_ti(lut, ksub, ti->grouped, M, ti->member, ti->start, ti->code2cc, ti->T, qcc,
+                   order, ti->visit, (method & VO_METHOD_EA) != 0, k, labels + (size_t)q * k,
+                   distances + (size_t)q * k, &pr);
+      pruned_sum += pr;
+    }
+    free(order);
+    free(qcc);
+    free(lut);
+  }
+  free(xp);
+  if (total_pruned) *total_pruned = pruned_sum;
+  return 0;
+}
+
 int vo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -116,6 +116,37 @@ void vo_query_lut_1d(const float *qproj, int ndim, const int *bits,
                      const uint16_t *codes, int64_t N, int code_cols, int k,
                      int *ids, float *dis);
 
+/* ---- triangle-inequality cluster pruning ---------------------------------
+ * VAQ::clusterTI (VAQ.cpp:878-999) after mTIClusters exists; the TI branch of
+ * VAQ::search (:799-826); VAQ::searchTriangleInequality (:1540-1692).
+ * PARITY UNPINNED (VAQ.cpp is unbuildable here); fvec_L2sqr_ny and the heap
+ * underneath are the pinned pieces.  std::sort ties are restated as stable
+ * (ascending row / cluster index). */
+#define VO_METHOD_TI 0x04u
+void vo_cluster_ti(const uint16_t *codes, int64_t N, int M, int L,
+                   const float *const *cent, const float *clusters, int T,
+                   int seg, int nthreads, int *member /*[N]*/,
+                   int *start /*[T+1]*/, float *code2cc /*[N], by original row*/,
+                   uint16_t *grouped /*[N x M] or NULL*/);
+void vo_ti_query_order(const float *qproj, const float *clusters, int T, int d,
+                       float *qcc /*[T]*/, int *order /*[T]*/);
+void vo_search_ti(const float *lut, int ksub, const uint16_t *grouped, int M,
+                  const int *member, const int *start, const float *code2cc,
+                  int T, const float *qcc, const int *order, float visit,
+                  int use_ea, int k, int *ids, float *dis, long *pruned_out);
+typedef struct {
+  const float *clusters;   /* mTIClusters, T x (seg*L) row-major            */
+  int T, seg;              /* mTIClusterNum, mTISegmentNum                  */
+  float visit;             /* mVisit                                        */
+  const int *member;       /* mTIClustersMember flattened (original rows)   */
+  const int *start;        /* mClusterMembersStartIdx + total, [T+1]        */
+  const float *code2cc;    /* mCodeToCCDist, by original row                */
+  const uint16_t *grouped; /* mCodebook after regrouping                    */
+} vo_ti;
+int vo_search_ti_all(const vo_index *ix, const vo_ti *ti, const float *X, int nq,
+                     int k, unsigned method, int nthreads, int projected,
+                     int *labels, float *distances, long *total_pruned);
+
 int vo_max_threads(void);
 
 #ifdef __cplusplus

@@ -14,7 +14,8 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libvaqhip.so")
 # every symbol include/vaqhip.h declares
 SYMBOLS = [
     "vaqhip_index_create", "vaqhip_index_create_ex", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
-    "vaqhip_index_set_codes_u16_device", "vaqhip_search", "vaqhip_search_projected",
+    "vaqhip_index_set_codes_u16_device", "vaqhip_index_set_ti_clusters", "vaqhip_index_set_method",
+    "vaqhip_search", "vaqhip_search_projected",
     "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
     "vaqhip_merge_topk_strided_device",
     "vaqhip_encode", "vaqhip_encode_device", "vaqhip_refine", "vaqhip_refine_device",
@@ -38,7 +39,8 @@ class Info(C.Structure):
     _fields_ = [("D", C.c_int), ("M", C.c_int), ("L", C.c_int), ("max_bits", C.c_int),
                 ("total_bits", C.c_int), ("code_bytes", C.c_int), ("algo_code_bytes", C.c_int),
                 ("lut_floats", C.c_int), ("N", C.c_int64), ("id_base", C.c_int64),
-                ("device_id", C.c_int), ("layout", C.c_int)]
+                ("device_id", C.c_int), ("layout", C.c_int), ("ti_clusters", C.c_int),
+                ("ti_segments", C.c_int), ("methods", C.c_uint), ("visit", C.c_float)]
 
 
 class Timing(C.Structure):
@@ -85,6 +87,8 @@ def load():
     L.vaqhip_index_destroy.restype = None
     L.vaqhip_index_set_codes_u16.argtypes = [vp, vp, i64, i64]
     L.vaqhip_index_set_codes_u16_device.argtypes = [vp, vp, i64, i64, vp]
+    L.vaqhip_index_set_ti_clusters.argtypes = [vp, vp, i32, i32]
+    L.vaqhip_index_set_method.argtypes = [vp, C.c_uint, C.c_float]
     L.vaqhip_search.argtypes = [vp, vp, i32, i32, vp, vp]
     L.vaqhip_search_projected.argtypes = [vp, vp, i32, i32, vp, vp]
     L.vaqhip_search_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]

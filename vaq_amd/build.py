@@ -13,31 +13,64 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vaq_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "vaq_amd", "lib")
 LIB = os.path.join(LIBDIR, "libvaqhip.so")
-SOURCES = ["vaq_kernels.hip", "vaqhip_api.cpp"]
-HEADERS = [os.path.join(CSRC, "vaq_kernels.h"), os.path.join(ROOT, "include", "vaqhip.h")]
+SOURCES = ["vaq_kernels.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
+KERNEL_HEADER = os.path.join(CSRC, "vaq_kernels.h")
+API_HEADER = os.path.join(ROOT, "include", "vaqhip.h")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _deps(src: str):
+    # only the host file sees the public C header
+    return [os.path.join(CSRC, src), KERNEL_HEADER] + ([API_HEADER] if src.endswith(".cpp") else [])
+OBJDIR = os.path.join(LIBDIR, "obj")
+
+
+def _flags_tag() -> str:
+    return os.environ.get("VAQ_EXTRA_FLAGS", "")
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+
+
+def _obj_stale(src: str) -> bool:
+    o = _obj(src)
+    if not os.path.exists(o):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(o)
+    tag = o + ".flags"
+    if not os.path.exists(tag) or open(tag).read() != _flags_tag():
+        return True
+    return any(os.path.getmtime(d) > t for d in _deps(src))
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
+    """Compile each translation unit to an object (in parallel, only the stale
+    ones) and link them into libvaqhip.so."""
+    os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-Wall",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += os.environ.get("VAQ_EXTRA_FLAGS", "").split()
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+              "-ffp-contract=off", "-fno-fast-math", "-Wall",
+              "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    extra = _flags_tag().split()
+    todo = [s for s in SOURCES if force or _obj_stale(s)]
+    procs = []
+    for s in todo:
+        cmd = common + extra + ["-c", os.path.join(CSRC, s), "-o", _obj(s)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, cmd, subprocess.Popen(cmd)))
+    failed = [s for s, _, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    for s in todo:
+        with open(_obj(s) + ".flags", "w") as f:
+            f.write(_flags_tag())
+    objs = [_obj(s) for s in SOURCES]
+    if todo or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return LIB
 
 

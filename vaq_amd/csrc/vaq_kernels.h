@@ -74,6 +74,16 @@ struct ScanParams {
   float *final_dist;
   int64_t id_base;
   int *part_cnt;          // [nq][n_slices] real entries of each list
+  // triangle-inequality form (VAQ::searchTriangleInequality): rows are grouped by cluster
+  // (bucket_start = cluster starts, n_buckets = clusters, farthest-from-centre first) and
+  // each query visits its own list of clusters; needs qb == 1 and ea == EA_QUEUE
+  int ti;                 // 1: TI form
+  const int *ti_order;    // [nq][n_buckets] clusters in visiting order
+  const float *ti_qcc;    // [nq][n_buckets] query-to-centre distances, same order
+  const int *ti_nvisit;   // [nq] clusters visited
+  const float *ti_xcc;    // [n_rows] row-to-centre distances (index order)
+  int ti_rowcap;          // rows taken from the visiting order (INT_MAX = all)
+  int sqrt_out;           // 1: results carry sqrt(distance) (VAQ.cpp:1583)
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
@@ -129,7 +139,24 @@ size_t merge_scratch_elems(int n_lists, int nq, int k);
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,
-                        unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st);
+                        unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st,
+                        int sqrt_out = 0);
+
+// ---- triangle-inequality cluster pruning (vaq_ti.hip) ----------------------
+// packed index rows -> uint16 N x M in original row order (inverse of launch_pack_codes)
+hipError_t launch_unpack_codes(const uint32_t *packed, int64_t n, int M, int layout, int W,
+                               const SubDesc *sub, const uint32_t *perm, uint16_t *out, hipStream_t st);
+// VAQ::clusterTI's regrouping: d_perm[n], d_start[T+1] (-1 for clusters that do not occur;
+// the caller back-fills), d_xcc_sorted[n].  Synchronises the stream.
+hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int seg, const SubDesc *sub,
+                         const float *cent, const float *d_clusters, int T, uint32_t *d_perm,
+                         int *d_start, float *d_xcc_sorted, hipStream_t st);
+// per query: cluster visiting order, the matching distances, clusters visited
+hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters, int T,
+                          const int *start, int max_visit, int k, int *order, float *qcc, int *nvisit,
+                          hipStream_t st);
+// extra LDS bytes of a TI scan workgroup
+size_t scan_ti_lds_bytes(int n_clusters);
 
 } // namespace vaq
 #endif

@@ -577,6 +577,17 @@ constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
 constexpr int HOT_SEG_STEPS = VAQ_HOT_SEG;  // wave steps per best-first work unit
 constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
 
+// TI form: begin / end / centre distance per visited cluster + unit prefix
+__host__ __device__ inline size_t ti_lds_bytes(int n_clusters) {
+  return ((size_t)n_clusters * 16 + 4 + 15) & ~(size_t)15;
+}
+// Slack of the TI bound: the reference prunes when bsfK <= qToCCDist - mCodeToCCDist
+// (VAQ.cpp:1566); both distances and the row sums carry fp32 rounding (a few ulp per
+// summed dimension), so the kernel only prunes when the bound clears the threshold by
+// 2^-13 of the operands -- then no admissible row can be lost and the result is the
+// exact k-min of the visited rows, whatever order the waves ran in.
+constexpr float TI_SLACK = 1.0f / 8192.0f;
+
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
 // LDS: [LUT][QB x selection state][per wave: survivor queue]
@@ -604,6 +615,12 @@ template <int QB> struct ScanCtx {
   unsigned *hot_mask;  // [HOT_MASK_WORDS] bit b set = bucket b is handled by the hot phase
   unsigned *hot_ticket;
   int n_hot;
+  // triangle-inequality form: the query's visiting list (QB == 1)
+  int *ti_begin;       // [nv] first index row of the i-th visited cluster
+  int *ti_end;         // [nv] one past the last row taken from it
+  float *ti_q;         // [nv] query-to-centre distance (qToCCDist)
+  int *ti_pre;         // [nv + 1] prefix of work-unit counts
+  int ti_nv;
 
   // Rank the buckets of the slice [r0, r1) by key = min over the batch's queries of
   // the first LUT term and keep the n_hot best.  Uses the (not yet staged) LUT
@@ -726,10 +743,72 @@ template <int QB> struct ScanCtx {
     hot_mask = reinterpret_cast<unsigned *>(hot_pre + HOT_MAX + 1);
     hot_ticket = hot_mask + HOT_MASK_WORDS;
     off += HOT_BYTES;
+    ti_nv = 0;
+    if (p.ti) {
+      ti_begin = reinterpret_cast<int *>(smem + off);
+      ti_end = ti_begin + p.n_buckets;
+      ti_q = reinterpret_cast<float *>(ti_end + p.n_buckets);
+      ti_pre = reinterpret_cast<int *>(ti_q + p.n_buckets);
+      off += ti_lds_bytes(p.n_buckets);
+    }
     const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
     unsigned char *qb = smem + off + (size_t)wave * q_bytes;
     q_id = reinterpret_cast<int *>(qb);
     q_p = reinterpret_cast<float *>(qb + (size_t)p.qcap * 4);
+  }
+
+  // TI form (VAQ::searchTriangleInequality, VAQ.cpp:1548-1560): the clusters this query
+  // visits, in order, with the rows taken from each (all of them, or what is left of the
+  // row budget) cut into work units of seg_rows rows aligned to the wave step.
+  __device__ __forceinline__ void stage_ti(const ScanParams &p, int seg_rows, int wstep, int tid,
+                                           int nthreads) {
+    const int T = p.n_buckets;
+    const int q = qi[0];
+    const int nv = p.ti_nvisit[q];
+    ti_nv = nv;
+    for (int i = tid; i < nv; i += nthreads) {
+      const int c = p.ti_order[(size_t)q * T + i];
+      ti_begin[i] = p.bucket_start[c];
+      ti_end[i] = p.bucket_start[c + 1];
+      ti_q[i] = p.ti_qcc[(size_t)q * T + i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      int carry_rows = 0, carry_units = 0;
+      for (int base = 0; base < nv; base += 64) {
+        const int i = base + lane;
+        const int b = i < nv ? ti_begin[i] : 0;
+        const int n = i < nv ? ti_end[i] - b : 0;
+        int inc = n;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(inc, o);
+          if (lane >= o) inc += v;
+        }
+        const int before = carry_rows + inc - n;  // rows of the clusters visited earlier
+        const int room = p.ti_rowcap > before ? p.ti_rowcap - before : 0;
+        const int take = n < room ? n : room;
+        const int e = b + take;
+        const int units = take > 0 ? (e - (b & ~(wstep - 1)) + seg_rows - 1) / seg_rows : 0;
+        int uinc = units;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int v = __shfl_up(uinc, o);
+          if (lane >= o) uinc += v;
+        }
+        if (i < nv) {
+          ti_end[i] = e;
+          ti_pre[i] = carry_units + uinc - units;
+        }
+        carry_rows += __builtin_amdgcn_readlane(inc, 63);
+        carry_units += __builtin_amdgcn_readlane(uinc, 63);
+      }
+      if (lane == 0) {
+        ti_pre[nv] = carry_units;
+        *hot_ticket = 0u;
+      }
+    }
+    __syncthreads();
   }
 
   // copy the batch's LUTs into LDS, interleaved per entry (after pick_hot, which borrows the region)
@@ -867,7 +946,7 @@ template <int QB> struct ScanCtx {
             const int id = sel[q].id[i];
             const bool ok = id != ID_SENTINEL;
             p.final_labels[o + i] = ok ? (int32_t)(id + p.id_base) : -1;
-            p.final_dist[o + i] = ok ? sel[q].d[i] : FLT_MAX;
+            p.final_dist[o + i] = ok ? (p.sqrt_out ? sqrtf(sel[q].d[i]) : sel[q].d[i]) : FLT_MAX;
           }
         } else {
           const size_t o = ((size_t)x * p.n_slices + slice) * k;
@@ -927,7 +1006,7 @@ template <int M> struct BytesItem {
 //       reference's order, abandoning after each, and admit to the k-min.
 // Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
-template <int M, int QB, int EA>
+template <int M, int QB, int EA, bool TI>
 __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
@@ -952,8 +1031,9 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
 
   ScanCtx<QB> cx;
   cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
-  if (EA != EA_NONE && cx.n_hot > 0)
+  if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
+  if (TI) cx.stage_ti(p, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
   cx.stage_lut(p, M * 256, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave;
@@ -1049,10 +1129,13 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     // work units (bucket b, rows [pos, be)): first the best-first segments, pulled by
     // ticket so that the waves share them, then this wave's own part of the slice in
     // natural order (minus the buckets already done)
-    bool hot_phase = cx.n_hot > 0;
+    bool hot_phase = !TI && cx.n_hot > 0;
     const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
+    const int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
+    int ti_cur = 0;
+    const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
-    if (w0 < w1) {
+    if (!TI && w0 < w1) {
       int lo = 0, hi = p.n_buckets;  // largest b with bstart[b] <= w0
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -1061,8 +1144,36 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
       wb = lo;
     }
     for (;;) {
-      int b, pos, be;
-      if (hot_phase) {
+      int b = 0, pos, be;
+      float qc = 0.0f;  // TI: distance from the query to the centre of the unit's cluster
+      if (TI) {
+        // work units of the visiting list, nearest clusters first, shared by ticket
+        // between the waves (and, unit u = ticket * n_slices + slice, between the
+        // workgroups serving this query)
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int64_t u64 = (int64_t)t * p.n_slices + slice;
+        if (u64 >= ti_total) break;
+        const int u = (int)u64;
+        int lo = ti_cur, hi = cx.ti_nv;  // largest i with ti_pre[i] <= u
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (cx.ti_pre[mid] <= u) lo = mid; else hi = mid;
+        }
+        ti_cur = lo;
+        const int bs = cx.ti_begin[lo], bend = cx.ti_end[lo];
+        qc = cx.ti_q[lo];
+        const int al = bs & ~(WSTEP - 1);
+        const int j = u - cx.ti_pre[lo];
+        pos = al + j * SEG_ROWS;
+        if (pos < bs) pos = bs;
+        be = al + (j + 1) * SEG_ROWS;
+        if (be > bend) be = bend;
+        pos = __builtin_amdgcn_readfirstlane(pos);  // (LDS reads land in VGPRs: tell the compiler
+        be = __builtin_amdgcn_readfirstlane(be);    //  these are wave-uniform)
+        qc = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(qc)));
+      } else if (hot_phase) {
         int t = 0;
         if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
@@ -1092,31 +1203,53 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
       {
         {
           // the bucket's first term dism = l0 (or its lower bound) is wave-uniform
-          const LT l0v = cx.lb[b];
           float l0[QB];
 #pragma unroll
-          for (int q = 0; q < QB; q++)
-            l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
-          if (cx.survives(l0)) {  // otherwise no row of the bucket can be admitted: skip its codes
+          for (int q = 0; q < QB; q++) l0[q] = 0.0f;
+          if (!TI) {
+            const LT l0v = cx.lb[b];
+#pragma unroll
+            for (int q = 0; q < QB; q++)
+              l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+          }
+          if (TI || cx.survives(l0)) {  // otherwise no row of the bucket can be admitted: skip its codes
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
             Item pf[PREFETCH];
+            float xpf[PREFETCH];  // TI: centre distance of each step's first row (wave-uniform)
 #pragma unroll
             for (int i = 0; i < PREFETCH; i++)
-              if (i < nst) pf[i].load(p.codes, (int64_t)((base0 + i * WSTEP) / Item::ROWS) + lane);
+              if (i < nst) {
+                pf[i].load(p.codes, (int64_t)((base0 + i * WSTEP) / Item::ROWS) + lane);
+                if (TI) xpf[i] = xcc[i == 0 ? pos : base0 + i * WSTEP];
+              }
             for (int t = 0; t < nst; t++) {
               const Item cur = pf[0];
+              const float xcur =
+                  TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
 #pragma unroll
-              for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
-              if (t + PREFETCH < nst)
+              for (int i = 0; i + 1 < PREFETCH; i++) {
+                pf[i] = pf[i + 1];
+                if (TI) xpf[i] = xpf[i + 1];
+              }
+              if (t + PREFETCH < nst) {
                 pf[PREFETCH - 1].load(p.codes, (int64_t)((base0 + (t + PREFETCH) * WSTEP) / Item::ROWS) + lane);
+                if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * WSTEP];
+              }
               const int base = base0 + t * WSTEP;
               cx.refresh(stepno++);
+              if (TI) {
+                // VAQ.cpp:1564-1568: rows of a cluster come farthest from the centre first, so
+                // the bound qc - xcc only grows from here on: once it clears the threshold the
+                // rest of the unit cannot hold an admissible row
+                const float bound = (qc - xcur) - TI_SLACK * (qc + xcur);
+                if (bound >= sqrtf(cx.thr_d[0])) break;
+              }
               const int row0 = base + lane * Item::ROWS;
               // A: dism = l0; dism += l1, every row of the item, all lanes
               float part[Item::ROWS][QB];
               bool alive[Item::ROWS];
-              if (cx.bshift == 0) {
+              if (!TI && cx.bshift == 0) {
 #pragma unroll
                 for (int r = 0; r < Item::ROWS; r++) {
 #pragma unroll
@@ -1177,7 +1310,7 @@ template <int W> struct BitsItem {
   }
 };
 
-template <int W, int QB, int EA, bool TAIL>
+template <int W, int QB, int EA, bool TAIL, bool TI>
 __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BitsItem<W> Item;
@@ -1198,8 +1331,9 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
 
   ScanCtx<QB> cx;
   cx.setup(smem, p, p.lut_lds_entries, qbatch, tid, nthreads);
-  if (EA != EA_NONE && cx.n_hot > 0)
+  if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
+  if (TI) cx.stage_ti(p, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
   cx.stage_lut(p, p.lut_lds_entries, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
@@ -1334,10 +1468,13 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
     const SubDesc s1 = sub[M > 1 ? 1 : 0], s2 = sub[M > 2 ? 2 : 0], s3 = sub[M > 3 ? 3 : 0];
     constexpr int WSTEP = TILE_ROWS;
     constexpr int SEG_ROWS = HOT_SEG_STEPS * WSTEP;
-    bool hot_phase = cx.n_hot > 0;
+    bool hot_phase = !TI && cx.n_hot > 0;
     const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
+    const int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
+    int ti_cur = 0;
+    const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
-    if (w0 < w1) {
+    if (!TI && w0 < w1) {
       int lo = 0, hi = p.n_buckets;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -1346,8 +1483,33 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
       wb = lo;
     }
     for (;;) {
-      int b, pos, be;
-      if (hot_phase) {
+      int b = 0, pos, be;
+      float qc = 0.0f;
+      if (TI) {  // see scan_bytes_body
+        int t = 0;
+        if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int64_t u64 = (int64_t)t * p.n_slices + slice;
+        if (u64 >= ti_total) break;
+        const int u = (int)u64;
+        int lo = ti_cur, hi = cx.ti_nv;
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (cx.ti_pre[mid] <= u) lo = mid; else hi = mid;
+        }
+        ti_cur = lo;
+        const int bs = cx.ti_begin[lo], bend = cx.ti_end[lo];
+        qc = cx.ti_q[lo];
+        const int al = bs & ~(WSTEP - 1);
+        const int j = u - cx.ti_pre[lo];
+        pos = al + j * SEG_ROWS;
+        if (pos < bs) pos = bs;
+        be = al + (j + 1) * SEG_ROWS;
+        if (be > bend) be = bend;
+        pos = __builtin_amdgcn_readfirstlane(pos);  // (LDS reads land in VGPRs: tell the compiler
+        be = __builtin_amdgcn_readfirstlane(be);    //  these are wave-uniform)
+        qc = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(qc)));
+      } else if (hot_phase) {
         int t = 0;
         if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
@@ -1376,32 +1538,52 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
       }
       {
         {
-          const LT l0v = cx.lb[b];  // first term (or its lower bound); subspace 0's table starts the packed LUT
           float l0[QB];
 #pragma unroll
-          for (int q = 0; q < QB; q++)
-            l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
-          if (cx.survives(l0)) {
+          for (int q = 0; q < QB; q++) l0[q] = 0.0f;
+          if (!TI) {
+            const LT l0v = cx.lb[b];  // first term (or its lower bound); subspace 0's table starts the packed LUT
+#pragma unroll
+            for (int q = 0; q < QB; q++)
+              l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+          }
+          if (TI || cx.survives(l0)) {
             const int base0 = pos & ~(TILE_ROWS - 1);
             const int nst = (be - base0 + TILE_ROWS - 1) / TILE_ROWS;
             Item pf[PREFETCH];
+            float xpf[PREFETCH];
 #pragma unroll
             for (int i = 0; i < PREFETCH; i++)
-              if (i < nst) pf[i].load(p.codes, base0 / TILE_ROWS + i, lane);
+              if (i < nst) {
+                pf[i].load(p.codes, base0 / TILE_ROWS + i, lane);
+                if (TI) xpf[i] = xcc[i == 0 ? pos : base0 + i * TILE_ROWS];
+              }
             for (int t = 0; t < nst; t++) {
               const Item cur = pf[0];
+              const float xcur =
+                  TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
 #pragma unroll
-              for (int i = 0; i + 1 < PREFETCH; i++) pf[i] = pf[i + 1];
-              if (t + PREFETCH < nst) pf[PREFETCH - 1].load(p.codes, base0 / TILE_ROWS + t + PREFETCH, lane);
+              for (int i = 0; i + 1 < PREFETCH; i++) {
+                pf[i] = pf[i + 1];
+                if (TI) xpf[i] = xpf[i + 1];
+              }
+              if (t + PREFETCH < nst) {
+                pf[PREFETCH - 1].load(p.codes, base0 / TILE_ROWS + t + PREFETCH, lane);
+                if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * TILE_ROWS];
+              }
               const int base = base0 + t * TILE_ROWS;
               cx.refresh(stepno++);
+              if (TI) {  // VAQ.cpp:1564-1568, see scan_bytes_body
+                const float bound = (qc - xcur) - TI_SLACK * (qc + xcur);
+                if (bound >= sqrtf(cx.thr_d[0])) break;
+              }
               const int row = base + lane;
               const uint32_t w0w = cur.w[0];
               const uint32_t w1w = W > 1 ? cur.w[W > 1 ? 1 : 0] : 0u;
               float acc[QB], dism[QB];
 #pragma unroll
               for (int q = 0; q < QB; q++) { acc[q] = l0[q]; dism[q] = l0[q]; }  // dism = l0 / dist = l0
-              if (cx.bshift > 0)  // coarse buckets: gather the row's own first term
+              if (TI || cx.bshift > 0)  // coarse buckets / TI clusters: gather the row's own first term
                 chain(0, lut[w0w & (unsigned)(s0c.ncent - 1)], acc, dism);
               // A: dism += l1 (field 1 lies inside dword 0)
               if (M > 1)
@@ -1516,27 +1698,37 @@ hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, 
 // __global__ entry points: the SGPR-capped one for EA_NONE / EA_QUEUE, a plain one for EA_INPLACE
 template <int M, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_kernel(ScanParams p) {
-  scan_bytes_body<M, QB, EA>(p);
+  scan_bytes_body<M, QB, EA, false>(p);
 }
 template <int M, int QB>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_inplace_kernel(ScanParams p) {
-  scan_bytes_body<M, QB, EA_INPLACE>(p);
+  scan_bytes_body<M, QB, EA_INPLACE, false>(p);
 }
 template <int W, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bits_kernel(ScanParams p) {
-  scan_bits_body<W, QB, EA, false>(p);
+  scan_bits_body<W, QB, EA, false, false>(p);
 }
 template <int W, int QB>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_inplace_kernel(ScanParams p) {
-  scan_bits_body<W, QB, EA_INPLACE, false>(p);
+  scan_bits_body<W, QB, EA_INPLACE, false, false>(p);
 }
-// tail LUT tables in global memory (big allocations); one form per early-abandon mode
+// some LUT tables left in global memory (TAIL): the rarely taken allocations with
+// more table entries than LDS holds
 template <int W, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_tail_kernel(ScanParams p) {
-  scan_bits_body<W, QB, EA, true>(p);
+  scan_bits_body<W, QB, EA, true, false>(p);
+}
+// triangle-inequality form (VAQ::searchTriangleInequality): one query per workgroup,
+// survivors queued; the bit-packed one always allows spilled tables
+template <int M>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_ti_kernel(ScanParams p) {
+  scan_bytes_body<M, 1, EA_QUEUE, true>(p);
+}
+template <int W>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_ti_kernel(ScanParams p) {
+  scan_bits_body<W, 1, EA_QUEUE, true, true>(p);
 }
 
-// ---- launch geometry shared with the host --------------------------------
 static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
 
 // rows the code buffer and every slice are padded to: one step of the largest workgroup
@@ -1561,6 +1753,8 @@ size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, 
   const size_t lbb = bucket_shift > 0 ? (((size_t)n_buckets * 4 * qb + 15) & ~(size_t)15) : 0;
   return lut + (size_t)qb * sb + lbb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
 }
+
+size_t scan_ti_lds_bytes(int n_clusters) { return ti_lds_bytes(n_clusters); }
 
 template <typename K>
 static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, int grid,
@@ -1607,8 +1801,31 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
-  const size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
-                                   p.bucket_shift);
+  size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
+                              p.bucket_shift);
+  if (p.ti) {
+    if (p.qb != 1 || p.ea != EA_QUEUE || p.bucket_shift != 0 || p.n_hot != 0) return hipErrorInvalidValue;
+    lds += ti_lds_bytes(p.n_buckets);
+    if (p.layout == LAYOUT_BYTES) {
+      switch (p.M) {
+      case 8:  return launch_scan_kernel(scan_bytes_ti_kernel<8>, p, lds, grid, st);
+      case 16: return launch_scan_kernel(scan_bytes_ti_kernel<16>, p, lds, grid, st);
+      case 32: return launch_scan_kernel(scan_bytes_ti_kernel<32>, p, lds, grid, st);
+      default: return hipErrorInvalidValue;
+      }
+    }
+    switch (p.W) {
+    case 1: return launch_scan_kernel(scan_bits_ti_kernel<1>, p, lds, grid, st);
+    case 2: return launch_scan_kernel(scan_bits_ti_kernel<2>, p, lds, grid, st);
+    case 3: return launch_scan_kernel(scan_bits_ti_kernel<3>, p, lds, grid, st);
+    case 4: return launch_scan_kernel(scan_bits_ti_kernel<4>, p, lds, grid, st);
+    case 5: return launch_scan_kernel(scan_bits_ti_kernel<5>, p, lds, grid, st);
+    case 6: return launch_scan_kernel(scan_bits_ti_kernel<6>, p, lds, grid, st);
+    case 7: return launch_scan_kernel(scan_bits_ti_kernel<7>, p, lds, grid, st);
+    case 8: return launch_scan_kernel(scan_bits_ti_kernel<8>, p, lds, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+  }
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes, 8)
@@ -1655,6 +1872,7 @@ constexpr int MERGE_FANIN = 16;  // lists folded by one workgroup (16 x k <= 204
 
 // grid = (query, group); group g folds lists [g*lists_per_group, ...).
 //  final != 0 : write labels (+id_base) / distances with -1 / FLT_MAX in empty slots
+//               (final == 2: distances as sqrt, the TI form's convention, VAQ.cpp:1583)
 //  final == 0 : write the group's k best as an intermediate list (raw ids, sentinels kept)
 //  thr_out    : optional [nq] float bits; receives min(thr_out[q], k-th distance) when k rows exist
 __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
@@ -1700,7 +1918,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
     const bool ok = i < kept && si[i] != ID_SENTINEL;
     if (final) {
       out_id[o + i] = ok ? (int32_t)(si[i] + id_base) : -1;
-      out_d[o + i] = ok ? sd[i] : FLT_MAX;
+      out_d[o + i] = ok ? (final == 2 ? sqrtf(sd[i]) : sd[i]) : FLT_MAX;
     } else {
       out_id[o + i] = ok ? si[i] : ID_SENTINEL;
       out_d[o + i] = ok ? sd[i] : INFINITY;
@@ -1845,7 +2063,7 @@ size_t merge_scratch_elems(int n_lists, int nq, int k) {
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k, int64_t id_base,
                         int in_final, int32_t *labels, float *dist, unsigned *thr_out,
-                        float *scratch_d, int *scratch_id, hipStream_t st) {
+                        float *scratch_d, int *scratch_id, hipStream_t st, int sqrt_out) {
   if (nq == 0 || k == 0) return hipSuccess;
   const float *cur_d = part_d;
   const int *cur_id = part_id;
@@ -1889,7 +2107,7 @@ hipError_t launch_merge(const float *part_d, const int *part_id, const int *part
   }
   hipLaunchKernelGGL(merge_kernel, dim3(nq, 1), dim3(MERGE_THREADS), 0, st, cur_d, cur_id, n_lists,
                      n_lists > 0 ? n_lists : 1, list_stride, query_stride, k, id_base, in_final,
-                     labels ? 1 : 0, labels ? labels : si, labels ? dist : sd, thr_out);
+                     labels ? (sqrt_out ? 2 : 1) : 0, labels ? labels : si, labels ? dist : sd, thr_out);
   return hipGetLastError();
 }
 

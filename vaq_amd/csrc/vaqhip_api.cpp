@@ -80,6 +80,12 @@ struct vaqhip_index {
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
   int bucket_shift = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
+  // triangle-inequality form (VAQ::clusterTI): rows grouped by cluster instead of by first
+  // code; d_bstart then holds the cluster starts, n_buckets = ti_T, bucket_shift = 0
+  int ti_T = 0, ti_seg = 0;
+  float ti_visit = 1.0f;              // mVisit
+  unsigned methods = VAQHIP_METHOD_HEAP;
+  DevBuf d_ti_clusters, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
@@ -222,6 +228,57 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   return VAQHIP_OK;
 }
 
+// Launch geometry of the TI form: one query per workgroup (Qb = 1, survivors queued), each
+// query's work units spread over `n_slices` workgroups when there are few queries.
+int make_ti_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
+  const int qb = 1, ea = vaq::EA_QUEUE;
+  const size_t ti_bytes = vaq::scan_ti_lds_bytes(ix->ti_T);
+  const int need = ix->layout == vaq::LAYOUT_BYTES ? ix->M : 1;
+  int best_nw = 0, best_waves = 0, subs = ix->M, entries = ix->lut_floats;
+  for (subs = ix->M; subs >= need; subs--) {
+    entries = subs == ix->M ? ix->lut_floats : ix->sub[subs].lut_off;
+    best_nw = 0;
+    best_waves = 0;
+    for (int nw : {4, 8, 16}) {
+      if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
+      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, nw, ix->ti_T, 0) + ti_bytes;
+      if (lds > LDS_LIMIT) continue;
+      const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
+      if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
+    }
+    if (best_nw) break;
+  }
+  if (!best_nw)
+    return fail(VAQHIP_EUNSUPPORTED,
+                "the lookup tables of the first %d subspaces, top-%d buffers and %d clusters do not fit "
+                "%zu B of LDS", need, k, ix->ti_T, LDS_LIMIT);
+  pl->lds_subs = subs;
+  pl->lut_lds_entries = entries;
+  pl->qb = qb;
+  pl->ea = ea;
+  pl->nwaves = best_nw;
+  vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, best_nw, ix->ti_T, 0) + ti_bytes;
+  int64_t s;
+  if (ix->opt_slices > 0) s = ix->opt_slices;
+  else {
+    // enough workgroups to fill the chip, but no more than the visited rows give work units
+    // (one unit = 16 wave steps) to two rounds of a workgroup's waves
+    const int64_t target = (int64_t)ix->n_cu * 8;
+    s = (target + nq - 1) / nq;
+    const int64_t unit_rows = 16 * (vaq::scan_wg_step_rows(ix->layout, ix->M) / vaq::SCAN_MAX_WAVES);
+    const double frac = ix->ti_visit < 1.0f ? std::max(ix->ti_visit, 1.0f / ix->ti_T) : 1.0;
+    const int64_t units = (int64_t)(frac * ((double)ix->N / unit_rows + ix->ti_T));
+    s = std::min<int64_t>(s, std::max<int64_t>(1, units / (2 * best_nw)));
+  }
+  pl->n_slices = (int)std::max<int64_t>(1, std::min<int64_t>(s, 4096));
+  pl->slice_rows = 0;
+  pl->seed_slices = 0;
+  pl->seed_rows = pl->seed_stride = 0;
+  pl->ordered = false;
+  return VAQHIP_OK;
+}
+
 int ensure_events(vaqhip_index *ix) {
   if (!ix->ev.empty()) return VAQHIP_OK;
   std::vector<hipEvent_t> ev(vaqhip_index::EV_SETS * 6);
@@ -234,6 +291,9 @@ int ensure_events(vaqhip_index *ix) {
 int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
                          int32_t *d_labels, float *d_dist, hipStream_t st) {
   if (ix->N < 0) return fail(VAQHIP_ESTATE, "search before codes were set");
+  if (((ix->methods & VAQHIP_METHOD_TI) != 0) != (ix->ti_T > 0))
+    return fail(VAQHIP_ESTATE, ix->ti_T > 0 ? "the rows are grouped by TI cluster: the method must include TI"
+                                             : "method TI needs vaqhip_index_set_ti_clusters first");
   if (nq < 0 || k <= 0) return fail(VAQHIP_EINVAL, "nq=%d k=%d", nq, k);
   if (k > VAQHIP_MAX_K) return fail(VAQHIP_EUNSUPPORTED, "k=%d > %d", k, VAQHIP_MAX_K);
   if (nq == 0) return VAQHIP_OK;
@@ -249,8 +309,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   }
   vaqhip_timing tm = {};
   Plan pl;
+  const bool ti = ix->ti_T > 0;
   {
-    int rc = make_plan(ix, std::min(nq, QUERY_CHUNK), k, &pl);
+    int rc = ti ? make_ti_plan(ix, std::min(nq, QUERY_CHUNK), k, &pl)
+                : make_plan(ix, std::min(nq, QUERY_CHUNK), k, &pl);
     if (rc) return rc;
   }
   const int chunk = std::min(nq, QUERY_CHUNK);
@@ -266,6 +328,12 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     const size_t ms = vaq::merge_scratch_elems(nslots, chunk, k);
     HIP_TRY(ix->w_ms_d.ensure(std::max<size_t>(ms, 1) * sizeof(float)));
     HIP_TRY(ix->w_ms_id.ensure(std::max<size_t>(ms, 1) * sizeof(int)));
+  }
+
+  if (ti) {
+    HIP_TRY(ix->w_ti_order.ensure((size_t)chunk * ix->ti_T * sizeof(int)));
+    HIP_TRY(ix->w_ti_qcc.ensure((size_t)chunk * ix->ti_T * sizeof(float)));
+    HIP_TRY(ix->w_ti_nvisit.ensure((size_t)chunk * sizeof(int)));
   }
 
   if (timing && nq > chunk)
@@ -318,9 +386,58 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.final_dist = nullptr;
     sp.slice_order = nullptr;
     sp.id_base = ix->id_base;
+    sp.ti = 0;
+    sp.ti_order = nullptr;
+    sp.ti_qcc = nullptr;
+    sp.ti_nvisit = nullptr;
+    sp.ti_xcc = nullptr;
+    sp.ti_rowcap = 0x7fffffff;
+    sp.sqrt_out = 0;
     int grid = 0;
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
+    if (ti) {
+      // VAQ::search's TI branch (VAQ.cpp:799-826) then VAQ::searchTriangleInequality (:1540-1692)
+      const int T = ix->ti_T;
+      const int max_visit = ix->ti_visit < 1.0f ? (int)((float)T * ix->ti_visit) : T;  // :1548-1551
+      HIP_TRY(vaq::launch_ti_plan(qp, n, ix->D, ix->ti_seg * ix->L, ix->d_ti_clusters.as<float>(), T,
+                                  ix->d_bstart.as<int>(), max_visit, k, ix->w_ti_order.as<int>(),
+                                  ix->w_ti_qcc.as<float>(), ix->w_ti_nvisit.as<int>(), st));
+      if (timing) HIP_TRY(hipEventRecord(ev[3], st));
+      sp.ti = 1;
+      sp.ti_order = ix->w_ti_order.as<int>();
+      sp.ti_qcc = ix->w_ti_qcc.as<float>();
+      sp.ti_nvisit = ix->w_ti_nvisit.as<int>();
+      sp.ti_xcc = ix->d_ti_xcc.as<float>();
+      // without EA the reference never admits a row after the first k of the visiting order
+      // (bsfKSquared stays 0, VAQ.cpp:1617-1686): reproduce that by taking only those rows
+      sp.ti_rowcap = (ix->methods & VAQHIP_METHOD_EA) ? 0x7fffffff : k;
+      sp.sqrt_out = 1;
+      sp.n_slices = pl.n_slices;
+      sp.slice_rows = 0;
+      sp.slice_stride = 0;
+      sp.share_thr = pl.n_slices > 1;
+      const bool direct = pl.n_slices == 1 && ix->N > 0;
+      if (direct) {
+        sp.final_labels = d_labels + (size_t)q0 * k;
+        sp.final_dist = d_dist + (size_t)q0 * k;
+      }
+      if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+      if (timing) HIP_TRY(hipEventRecord(ev[4], st));
+      if (!direct)
+        HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, nullptr, ix->N > 0 ? pl.n_slices : 0, k,
+                                  (int64_t)pl.n_slices * k, n, k, ix->id_base, 0,
+                                  d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, nullptr,
+                                  ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st, 1));
+      if (timing) HIP_TRY(hipEventRecord(ev[5], st));
+      tm.seed_slices = 0;
+      tm.queries_per_pass = 1;
+      tm.slices = pl.n_slices;
+      tm.workgroups = grid;
+      tm.passes = n;
+      tm.lds_bytes = (int)pl.lds;
+      continue;
+    }
     if (ix->N > 0 && pl.seed_slices > 0) {
       sp.n_slices = pl.seed_slices;
       sp.slice_rows = pl.seed_rows;
@@ -508,6 +625,56 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
   delete ix;
 }
 
+// Order the N rows of the device matrix d_u16 (CodebookType layout) -- by first code, or by TI
+// cluster when clusters are set -- and pack them.  Synchronises the stream.
+static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStream_t st) {
+  const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
+  const int64_t padded = std::max<int64_t>(step, ((N + step - 1) / step) * step);
+  const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
+  HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
+  const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
+  int shift = 0, K0 = 1;
+  if (ix->ti_T > 0) {
+    K0 = ix->ti_T;
+  } else {
+    // bucket = top bits of the first code, coarse enough that buckets average >= ~2048 rows
+    // (at most 4096 buckets; at most 1024 when coarser than the code itself)
+    int kb = ix->bits[0];
+    while (kb > 4 && ((int64_t)1 << kb) * 2048 > std::max<int64_t>(N, 1)) kb--;
+    if (kb > 12) kb = 12;
+    if (kb < ix->bits[0] && kb > 10) kb = 10;
+    shift = ix->bits[0] - kb;
+    K0 = 1 << kb;
+  }
+  HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
+  HIP_TRY(ix->d_perm.ensure(std::max<size_t>((size_t)N, 1) * sizeof(uint32_t)));
+  if (ix->ti_T > 0) HIP_TRY(ix->d_ti_xcc.ensure(std::max<size_t>((size_t)padded, 1) * sizeof(float)));
+  std::vector<int> bstart((size_t)K0 + 1, (int)N);
+  if (N == 0) {
+    HIP_TRY(hipMemsetAsync(ix->d_codes.p, 0, (size_t)words * sizeof(uint32_t), st));
+  } else {
+    if (ix->ti_T > 0)
+      HIP_TRY(vaq::ti_group_rows(d_u16, N, ix->M, ix->L, ix->ti_seg, dsub, ix->d_cent.as<float>(),
+                                 ix->d_ti_clusters.as<float>(), ix->ti_T, ix->d_perm.as<uint32_t>(),
+                                 ix->d_bstart.as<int>(), ix->d_ti_xcc.as<float>(), st));
+    else
+      HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->d_perm.as<uint32_t>(),
+                                      ix->d_bstart.as<int>(), st));
+    HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    bstart[K0] = (int)N;
+    for (int b = K0 - 1; b >= 0; b--)
+      if (bstart[b] < 0) bstart[b] = bstart[b + 1];  // codes / clusters that do not occur: empty
+    HIP_TRY(vaq::launch_pack_codes(d_u16, 0, N, padded, ix->M, ix->layout, ix->W, dsub,
+                                   ix->d_perm.as<uint32_t>(), ix->d_codes.as<uint32_t>(), st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+  ix->N = N;
+  ix->bucket_shift = shift;
+  ix->n_buckets = K0;
+  return VAQHIP_OK;
+}
+
 static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_device, int64_t N,
                             int64_t id_base, hipStream_t st) {
   if (!ix) return fail(VAQHIP_EINVAL, "index is null");
@@ -519,52 +686,21 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   std::lock_guard<std::mutex> lk(ix->mu);
   DeviceGuard g(ix->device);
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
-  const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
-  const int64_t padded = std::max<int64_t>(step, ((N + step - 1) / step) * step);
-  const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
-  HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
-  const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
-  // bucket = top bits of the first code, coarse enough that buckets average >= ~2048 rows
-  // (at most 4096 buckets; at most 1024 when coarser than the code itself)
-  int kb = ix->bits[0];
-  while (kb > 4 && ((int64_t)1 << kb) * 2048 > std::max<int64_t>(N, 1)) kb--;
-  if (kb > 12) kb = 12;
-  if (kb < ix->bits[0] && kb > 10) kb = 10;
-  const int shift = ix->bits[0] - kb;
-  const int K0 = 1 << kb;
-  HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
-  HIP_TRY(ix->d_perm.ensure(std::max<size_t>((size_t)N, 1) * sizeof(uint32_t)));
-  std::vector<int> bstart((size_t)K0 + 1, (int)N);
-  if (N == 0) {
-    HIP_TRY(hipMemsetAsync(ix->d_codes.p, 0, (size_t)words * sizeof(uint32_t), st));
-  } else {
-    // all rows must be resident to sort them: stage a host matrix on the device first
-    DevBuf staged;
-    const uint16_t *d_u16 = codes;
-    if (!on_device) {
-      HIP_TRY(staged.ensure((size_t)N * ix->M * sizeof(uint16_t)));
-      for (int64_t r = 0; r < N; r += UPLOAD_CHUNK_ROWS) {
-        const int64_t e = std::min(N, r + UPLOAD_CHUNK_ROWS);
-        HIP_TRY(hipMemcpyAsync(staged.as<uint16_t>() + r * ix->M, codes + r * ix->M,
-                               (size_t)(e - r) * ix->M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
-      }
-      d_u16 = staged.as<uint16_t>();
+  // all rows must be resident to sort them: stage a host matrix on the device first
+  DevBuf staged;
+  const uint16_t *d_u16 = codes;
+  if (!on_device && N > 0) {
+    HIP_TRY(staged.ensure((size_t)N * ix->M * sizeof(uint16_t)));
+    for (int64_t r = 0; r < N; r += UPLOAD_CHUNK_ROWS) {
+      const int64_t e = std::min(N, r + UPLOAD_CHUNK_ROWS);
+      HIP_TRY(hipMemcpyAsync(staged.as<uint16_t>() + r * ix->M, codes + r * ix->M,
+                             (size_t)(e - r) * ix->M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->d_perm.as<uint32_t>(),
-                                    ix->d_bstart.as<int>(), st));
-    HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
-    bstart[K0] = (int)N;
-    for (int b = K0 - 1; b >= 0; b--)
-      if (bstart[b] < 0) bstart[b] = bstart[b + 1];  // codes that do not occur: empty bucket
-    HIP_TRY(vaq::launch_pack_codes(d_u16, 0, N, padded, ix->M, ix->layout, ix->W, dsub,
-                                   ix->d_perm.as<uint32_t>(), ix->d_codes.as<uint32_t>(), st));
-    HIP_TRY(hipStreamSynchronize(st));  // `staged` is freed on return
+    d_u16 = staged.as<uint16_t>();
   }
-  HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
-  ix->N = N;
+  int rc = build_rows(ix, d_u16, N, st);  // synchronises: `staged` is freed on return
+  if (rc) return rc;
   ix->id_base = id_base;
-  ix->bucket_shift = shift;
-  ix->n_buckets = K0;
   return VAQHIP_OK;
 }
 
@@ -822,6 +958,62 @@ int vaqhip_refine(int device_id, const float *queries, int nq, int D, const floa
   return VAQHIP_OK;
 }
 
+int vaqhip_index_set_ti_clusters(vaqhip_index *ix, const float *clusters, int T, int seg_num) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (T < 0 || (T > 0 && !clusters)) return fail(VAQHIP_EINVAL, "bad clusters/T");
+  if (T > VAQHIP_MAX_TI_CLUSTERS)
+    return fail(VAQHIP_EUNSUPPORTED, "T=%d > %d clusters", T, VAQHIP_MAX_TI_CLUSTERS);
+  if (T > 0 && (seg_num < 1 || seg_num > ix->M))
+    return fail(VAQHIP_EINVAL, "seg_num=%d outside 1..%d", seg_num, ix->M);
+  if (T > 0 && (int64_t)seg_num * ix->L > 1024)
+    return fail(VAQHIP_EUNSUPPORTED, "TI centres of %d dims (> 1024)", seg_num * ix->L);
+  if (T > 0 && ix->seq) return fail(VAQHIP_EINVAL, "TI is a VAQ::search method, not a queryLUT one");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  if (T == 0 && ix->ti_T == 0) return VAQHIP_OK;
+  hipStream_t st = ix->stream;
+  // rows already handed over: recover them in original order, then regroup
+  DevBuf rows;
+  if (ix->N > 0) {
+    HIP_TRY(rows.ensure((size_t)ix->N * ix->M * sizeof(uint16_t)));
+    HIP_TRY(vaq::launch_unpack_codes(ix->d_codes.as<uint32_t>(), ix->N, ix->M, ix->layout, ix->W,
+                                     ix->d_sub.as<vaq::SubDesc>(), ix->d_perm.as<uint32_t>(),
+                                     rows.as<uint16_t>(), st));
+  }
+  if (T > 0) {
+    const size_t bytes = (size_t)T * seg_num * ix->L * sizeof(float);
+    HIP_TRY(ix->d_ti_clusters.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(ix->d_ti_clusters.p, clusters, bytes, hipMemcpyHostToDevice, st));
+  }
+  ix->ti_T = T;
+  ix->ti_seg = T > 0 ? seg_num : 0;
+  if (T > 0) ix->methods |= VAQHIP_METHOD_TI;
+  else {
+    ix->methods &= ~VAQHIP_METHOD_TI;
+    if (!ix->methods) ix->methods = VAQHIP_METHOD_HEAP;
+  }
+  if (ix->N >= 0) {
+    int rc = build_rows(ix, rows.as<uint16_t>(), ix->N, st);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return VAQHIP_OK;
+}
+
+int vaqhip_index_set_method(vaqhip_index *ix, unsigned methods, float visit) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (methods & ~(VAQHIP_METHOD_EA | VAQHIP_METHOD_TI | VAQHIP_METHOD_HEAP))
+    return fail(VAQHIP_EUNSUPPORTED, "method bits 0x%x: only HEAP, EA and TI are on this path", methods);
+  if (!(methods & (VAQHIP_METHOD_EA | VAQHIP_METHOD_TI | VAQHIP_METHOD_HEAP)))
+    return fail(VAQHIP_EUNSUPPORTED, "no search method selected (SORT is not provided)");
+  if (!(visit > 0.0f)) return fail(VAQHIP_EINVAL, "visit must be > 0");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  ix->methods = methods;
+  ix->ti_visit = visit;
+  return VAQHIP_OK;
+}
+
 int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out) {
   if (!ix || !out) return fail(VAQHIP_EINVAL, "null pointer");
   out->D = ix->D;
@@ -836,6 +1028,10 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out) {
   out->id_base = ix->id_base;
   out->device_id = ix->device;
   out->layout = ix->layout;
+  out->ti_clusters = ix->ti_T;
+  out->ti_segments = ix->ti_seg;
+  out->methods = ix->methods;
+  out->visit = ix->ti_visit;
   return VAQHIP_OK;
 }
 

@@ -73,16 +73,24 @@ class VaqHip:
         self.mCentroidsPerSubs: List[np.ndarray] = []
         self.mBitsAlloc: List[int] = []
         self.mCodebook: Optional[np.ndarray] = None
+        # VAQ.hpp:77-84: triangle-inequality clusters
+        self.mTIClusterNum = 0
+        self.mTISegmentNum = -1
+        self.mTIVariance = 1.0
+        self.mVisit = 1.0
+        self.mTIClusters: Optional[np.ndarray] = None  # T x (mTISegmentNum * mSubsLen)
         self.id_base = 0
         self._h = C.c_void_p()
         self._sig = None
         self._codes_sig = None
+        self._ti_sig = None
+        self._method_sig = None
 
     # ------------------------------------------------------------ parsing --
     def parseMethodString(self, methodString: str) -> None:
-        """VAQ::parseMethodString (VAQ.cpp:1189-1267).  HEAP and EA select the
-        scan on this path; the other tokens the reference accepts (SORT, TI*,
-        FAST*) are outside it and raise."""
+        """VAQ::parseMethodString (VAQ.cpp:1189-1267).  HEAP, EA and TI<T>[m<seg>]
+        select the scans on this path; the other tokens the reference accepts
+        (SORT, FAST*) are outside it and raise."""
         for token in methodString.split(","):
             if token.startswith("VAQ"):
                 m = re.match(r"VAQ(\d+)m(\d+)min(\d+)max(\d+)var([0-9.]+)", token)
@@ -102,17 +110,31 @@ class VaqHip:
                     elif "EA" in t:
                         methods |= NNMethod.EA
                     elif "TI" in t:
-                        methods |= NNMethod.TI
+                        # VAQ.cpp:1236-1251: TI<T>var<v> | TI<T>m<seg> | TI<T>
+                        mv = re.match(r"TI(\d+)var([0-9.]+)", t)
+                        mm = re.match(r"TI(\d+)m(\d+)", t)
+                        m1 = re.match(r"TI(\d+)", t)
+                        if mv:
+                            methods |= NNMethod.TI
+                            self.mTIClusterNum = int(mv.group(1))
+                            self.mTIVariance = float(mv.group(2))
+                        elif mm:
+                            methods |= NNMethod.TI
+                            self.mTIClusterNum = int(mm.group(1))
+                            self.mTISegmentNum = int(mm.group(2))
+                        elif m1:
+                            methods |= NNMethod.TI
+                            self.mTIClusterNum = int(m1.group(1))
                     elif "FAST3" in t:
                         methods |= NNMethod.Fast3
                     elif "FAST2" in t:
                         methods |= NNMethod.Fast2
                     elif "FAST" in t:
                         methods |= NNMethod.Fast
-                unsupported = methods & ~(NNMethod.Heap | NNMethod.EA)
+                unsupported = methods & ~(NNMethod.Heap | NNMethod.EA | NNMethod.TI)
                 if unsupported:
                     raise _lib.VaqHipError(-2, f"search method bits 0x{unsupported:02x} in "
-                                               f"'{token}' are outside the HEAP/EA path")
+                                               f"'{token}' are outside the HEAP/EA/TI path")
                 self.mMethods = methods
 
     def searchMethod(self) -> int:
@@ -167,9 +189,69 @@ class VaqHip:
         self._h = h
         self._sig = sig
         self._codes_sig = None
+        self._ti_sig = None
+        self._method_sig = None
+
+    # ---------------------------------------------------------------- TI --
+    def decodeFirstSegments(self, rows: np.ndarray, seg: int) -> np.ndarray:
+        """Rows of mCodebook as the vectors clusterTI works on: the centroids of
+        their first `seg` codes side by side (VAQ.cpp:926-933)."""
+        cb = np.asarray(self.mCodebook)[rows]
+        return np.concatenate([np.asarray(self.mCentroidsPerSubs[s], np.float32)[cb[:, s].astype(np.int64)]
+                               for s in range(seg)], axis=1)
+
+    def clusterTI(self, useKMeans: bool = False, verbose: bool = False, seed: int = 13517106) -> None:
+        """VAQ::clusterTI (VAQ.hpp:106, VAQ.cpp:878-999).  Makes mTIClusters when it
+        is not set yet -- useKMeans=False: mTIClusterNum random code rows, decoded
+        (VAQ.cpp:901-911); True: k-means over decoded code rows (:897-900, at most
+        256 rows per centre as KMeans::staticFitCodebook samples) -- and leaves the
+        grouping itself (:913-996) to the GPU at the next search."""
+        if self.mTIVariance < 1:
+            raise _lib.VaqHipError(-2, "TI<T>var<v> needs train()'s variance profile; use TI<T>m<seg>")
+        seg = self.mTISegmentNum if self.mTISegmentNum != -1 else self.mHighestSubs  # :890-892
+        self.mTISegmentNum = seg
+        if self.mTIClusters is None:
+            if self.mCodebook is None or hasattr(self.mCodebook, "data_ptr"):
+                raise _lib.VaqHipError(-7, "clusterTI needs a host mCodebook (or set mTIClusters)")
+            T = self.mTIClusterNum
+            N = self.mCodebook.shape[0]
+            rng = np.random.default_rng(seed)
+            if not useKMeans:
+                self.mTIClusters = self.decodeFirstSegments(rng.integers(0, N, size=T), seg)
+            else:
+                import torch
+                from . import harness
+                n = min(N, 256 * T)
+                X = self.decodeFirstSegments(rng.permutation(N)[:n], seg)
+                dev = "cuda" if torch.cuda.is_available() else "cpu"
+                self.mTIClusters = harness.kmeans(torch.from_numpy(X).to(dev), T, iters=50,
+                                                  seed=seed).cpu().numpy()
+        self.mMethods |= NNMethod.TI
+
+    def _ensure_ti(self):
+        L = _lib.load()
+        if self.mMethods & NNMethod.TI:
+            if self.mTIClusters is None:
+                raise _lib.VaqHipError(-7, "method TI: call clusterTI() or set mTIClusters first")
+            cl = np.ascontiguousarray(self.mTIClusters, dtype=np.float32)
+            seg = self.mTISegmentNum if self.mTISegmentNum != -1 else self.mHighestSubs
+            if cl.ndim != 2 or cl.shape[1] != seg * self.mSubsLen:
+                raise _lib.VaqHipError(-1, f"mTIClusters {cl.shape} is not T x {seg * self.mSubsLen}")
+            sig = (id(self.mTIClusters), seg)
+            if sig != self._ti_sig:
+                _lib.check(L.vaqhip_index_set_ti_clusters(self._h, _ptr(cl), cl.shape[0], seg))
+                self._ti_sig = sig
+        elif self._ti_sig is not None:
+            _lib.check(L.vaqhip_index_set_ti_clusters(self._h, None, 0, 0))
+            self._ti_sig = None
+        msig = (self.mMethods, float(self.mVisit))
+        if msig != self._method_sig:
+            _lib.check(L.vaqhip_index_set_method(self._h, self.mMethods, float(self.mVisit)))
+            self._method_sig = msig
 
     def _ensure_codes(self):
         self._ensure_index()
+        self._ensure_ti()  # before the codes: they are then grouped once, not twice
         if self.mCodebook is None:
             if self._codes_sig is not None:
                 return  # the packed copy already lives on the device (host copy was dropped)
@@ -197,10 +279,10 @@ class VaqHip:
     # ------------------------------------------------------------- search --
     def search(self, XTest: np.ndarray, k: int, verbose: bool = False,
                projected: bool = False) -> LabelDistVec:
-        """VAQ::search (VAQ.cpp:776-847): flat labels / squared distances,
-        ascending per query."""
-        if not (self.mMethods & (NNMethod.Heap | NNMethod.EA)):
-            raise _lib.VaqHipError(-2, "only HEAP / EA are implemented on this path")
+        """VAQ::search (VAQ.cpp:776-847): flat labels / distances, ascending per
+        query; squared for HEAP / EA, square roots with TI (VAQ.cpp:1583)."""
+        if not (self.mMethods & (NNMethod.Heap | NNMethod.EA | NNMethod.TI)):
+            raise _lib.VaqHipError(-2, "only HEAP / EA / TI are implemented on this path")
         self._ensure_codes()
         X = np.ascontiguousarray(XTest, dtype=np.float32)
         if X.ndim != 2 or X.shape[1] != self.mTotalDim:
