@@ -9,6 +9,8 @@
 //               --queries q.fvecs --timeseries-size 128 [--queries-size N] \
 //               --method VAQ64m8min8max8var1,HEAP --k 100 \
 //               [--groundtruth gt.ivecs] [--result out.csv] [--bits 8,8,...]
+//               [--visit-cluster 0.25]     (demo_vaq.cpp:43,57; with a ...,EA_TI<T>m<seg> method)
+//               [--ti-clusters c.f32]      (raw T x seg*L float32; default: random decoded rows)
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -48,6 +50,16 @@ int main(int argc, char **argv) {
       vaq.mEigenVectors = RowMatrixF(D, D);
       detail::File f(a["eigen"], "rb");
       f.read(vaq.mEigenVectors.data(), sizeof(float), (size_t)D * D);
+    }
+    if (vaq.searchMethod() & VaqHip::NNMethod::TI) {  // demo_vaq.cpp:57, :263-267
+      if (a.count("visit-cluster")) vaq.mVisit = (float)std::atof(a["visit-cluster"].c_str());
+      if (vaq.mTISegmentNum == -1) vaq.mTISegmentNum = M;
+      if (a.count("ti-clusters")) {
+        vaq.mTIClusters = RowMatrixF((size_t)vaq.mTIClusterNum, (size_t)vaq.mTISegmentNum * vaq.mSubsLen());
+        detail::File f(a["ti-clusters"], "rb");
+        f.read(vaq.mTIClusters.data(), sizeof(float), vaq.mTIClusters.rows() * vaq.mTIClusters.cols());
+      }
+      vaq.clusterTI(false, true);
     }
     RowMatrixF queries = readFVecs(a["queries"], N, std::atoi(a["queries-size"].c_str()), D - N);
     const int k = std::atoi(a["k"].c_str());

@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -73,6 +74,13 @@ public:
   std::vector<RowMatrixF> mCentroidsPerSubs;  // K_s x L each
   std::vector<int> mBitsAlloc;
   CodebookType mCodebook;                     // N x M uint16
+  // VAQ.hpp:77-84: triangle-inequality clusters.  mTIClusters is T x (mTISegmentNum * mSubsLen);
+  // the reference fills it in clusterTI() with a k-means over decoded codes -- here the caller
+  // provides it (like the codebooks), or clusterTI(false) draws random decoded rows.
+  int mTIClusterNum = 0, mTISegmentNum = -1;
+  float mTIVariance = 1.0f;
+  float mVisit = 1.0f;
+  RowMatrixF mTIClusters;
   int64_t mIdBase = 0;                        // shard offset (not in the reference: single node)
   int mDevice = 0;
 
@@ -86,8 +94,8 @@ public:
   int mTotalDim() const { return mHighestSubs() * mSubsLen(); }
   uint32_t searchMethod() const { return mMethods; }  // VAQ.hpp:106-108
 
-  // VAQ::parseMethodString, VAQ.cpp:1189-1267.  HEAP and EA are this path;
-  // other search tokens throw (the reference would run a different algorithm).
+  // VAQ::parseMethodString, VAQ.cpp:1189-1267.  HEAP, EA and TI<T>[m<seg>] are this
+  // path; other search tokens throw (the reference would run a different algorithm).
   void parseMethodString(const std::string &methodString) {
     std::stringstream ss(methodString);
     std::string token;
@@ -109,13 +117,23 @@ public:
           if (t.find("SORT") != std::string::npos) m |= NNMethod::Sort;
           else if (t.find("HEAP") != std::string::npos) m |= NNMethod::Heap;
           else if (t.find("EA") != std::string::npos) m |= NNMethod::EA;
-          else if (t.find("TI") != std::string::npos) m |= NNMethod::TI;
+          else if (t.find("TI") != std::string::npos) {  // VAQ.cpp:1236-1251
+            unsigned long cluster = 0, segment = 0;
+            float minvar = 1.0f;
+            if (std::sscanf(t.c_str(), "TI%luvar%f", &cluster, &minvar) == 2) {
+              m |= NNMethod::TI; mTIClusterNum = (int)cluster; mTIVariance = minvar;
+            } else if (std::sscanf(t.c_str(), "TI%lum%lu", &cluster, &segment) == 2) {
+              m |= NNMethod::TI; mTIClusterNum = (int)cluster; mTISegmentNum = (int)segment;
+            } else if (std::sscanf(t.c_str(), "TI%lu", &cluster) == 1) {
+              m |= NNMethod::TI; mTIClusterNum = (int)cluster;
+            }
+          }
           else if (t.find("FAST3") != std::string::npos) m |= NNMethod::Fast3;
           else if (t.find("FAST2") != std::string::npos) m |= NNMethod::Fast2;
           else if (t.find("FAST") != std::string::npos) m |= NNMethod::Fast;
         }
-        if (m & ~(uint32_t)(NNMethod::Heap | NNMethod::EA))
-          throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: method '" + token + "' is outside the HEAP/EA path");
+        if (m & ~(uint32_t)(NNMethod::Heap | NNMethod::EA | NNMethod::TI))
+          throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: method '" + token + "' is outside the HEAP/EA/TI path");
         mMethods = m;
       }
     }
@@ -135,7 +153,19 @@ public:
       check(vaqhip_index_create(&h_, mTotalDim(), M, mBitsAlloc.data(), cp.data(),
                                 mEigenVectors.rows() ? mEigenVectors.data() : nullptr, mDevice));
       codes_set_ = false;
+      ti_set_ = false;
     }
+    if ((mMethods & NNMethod::TI) && !ti_set_) {  // before the codes: they are then grouped once
+      const int seg = mTISegmentNum == -1 ? M : mTISegmentNum;  // VAQ.cpp:890-892
+      if (mTIClusters.rows() == 0 || (int)mTIClusters.cols() != seg * mSubsLen())
+        throw Error(VAQHIP_ESTATE, "vaqhip: method TI needs mTIClusters (T x seg*L); see clusterTI()");
+      check(vaqhip_index_set_ti_clusters(h_, mTIClusters.data(), (int)mTIClusters.rows(), seg));
+      ti_set_ = true;
+    } else if (!(mMethods & NNMethod::TI) && ti_set_) {
+      check(vaqhip_index_set_ti_clusters(h_, nullptr, 0, 0));
+      ti_set_ = false;
+    }
+    check(vaqhip_index_set_method(h_, mMethods, mVisit));
     if (!codes_set_) {
       if (mCodebook.cols() != (size_t)M && mCodebook.rows() != 0)
         throw Error(VAQHIP_EINVAL, "vaqhip: mCodebook is not N x M");
@@ -148,13 +178,40 @@ public:
     vaqhip_index_destroy(h_);
     h_ = nullptr;
     codes_set_ = false;
+    ti_set_ = false;
+  }
+
+  // VAQ::clusterTI, VAQ.hpp:106 / VAQ.cpp:878-999.  useKMeans = false is the reference's
+  // other branch (:901-911): mTIClusterNum random code rows, decoded over the first
+  // mTISegmentNum subspaces.  The reference's k-means branch (:897-900) is training and
+  // is not provided: fill mTIClusters yourself for that.  The grouping itself happens
+  // on the GPU at the next search().
+  void clusterTI(bool useKMeans = false, bool verbose = false) {
+    (void)verbose;
+    if (mTIVariance < 1.0f)
+      throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: TI<T>var<v> needs train()'s variance profile; use TI<T>m<seg>");
+    if (mTISegmentNum == -1) mTISegmentNum = mHighestSubs();
+    if (mTIClusters.rows() == 0) {
+      if (useKMeans)
+        throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: the k-means of clusterTI is training; set mTIClusters");
+      if (mCodebook.rows() == 0) throw Error(VAQHIP_ESTATE, "vaqhip: clusterTI needs mCodebook");
+      const int L = mSubsLen();
+      mTIClusters = RowMatrixF((size_t)mTIClusterNum, (size_t)mTISegmentNum * L);
+      for (int i = 0; i < mTIClusterNum; i++) {
+        const size_t r = (size_t)std::rand() % mCodebook.rows();  // VAQ.cpp:903
+        for (int s = 0; s < mTISegmentNum; s++)
+          for (int j = 0; j < L; j++) mTIClusters(i, (size_t)s * L + j) = mCentroidsPerSubs[s](mCodebook(r, s), j);
+      }
+    }
+    mMethods |= NNMethod::TI;
+    ti_set_ = false;
   }
 
   // VAQ::search, VAQ.hpp:102 / VAQ.cpp:776-847
   template <class Mat> LabelDistVecF search(const Mat &XTest, const int k, bool verbose = false) {
     (void)verbose;
-    if (!(mMethods & (NNMethod::Heap | NNMethod::EA)))
-      throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: only HEAP / EA are implemented on this path");
+    if (!(mMethods & (NNMethod::Heap | NNMethod::EA | NNMethod::TI)))
+      throw Error(VAQHIP_EUNSUPPORTED, "vaqhip: only HEAP / EA / TI are implemented on this path");
     sync();
     LabelDistVecF ret;
     const size_t nq = (size_t)XTest.rows();
@@ -221,6 +278,7 @@ public:
 private:
   vaqhip_index *h_ = nullptr;
   bool codes_set_ = false;
+  bool ti_set_ = false;
 };
 
 // ---------------------------------------------------------------------------

@@ -69,7 +69,14 @@ def test_parse_method_string():
     assert v.mMethods == vaq_amd.NNMethod.Heap
     v.parseMethodString("VAQ64m16min3max6var0.99,EA")
     assert v.mMethods == vaq_amd.NNMethod.EA and abs(v.mPercentVarExplained - 0.99) < 1e-6
+    v.parseMethodString("VAQ128m32min6max9var0.95,EA_TI200")
+    assert v.mMethods == (vaq_amd.NNMethod.EA | vaq_amd.NNMethod.TI)
+    assert (v.mTIClusterNum, v.mTISegmentNum) == (200, -1)
+    v.parseMethodString("VAQ256m32min7max10var1,EA_TI1000m16")
+    assert (v.mTIClusterNum, v.mTISegmentNum) == (1000, 16)
+    v.parseMethodString("VAQ256m32min7max10var1,TI500var0.9")
+    assert v.mMethods == vaq_amd.NNMethod.TI and v.mTIClusterNum == 500 and abs(v.mTIVariance - 0.9) < 1e-6
     with pytest.raises(vaq_amd.VaqHipError):
-        v.parseMethodString("VAQ128m32min6max9var0.95,EA_TI200")
+        v.parseMethodString("VAQ128m32min6max9var0.95,SORT")
     with pytest.raises(vaq_amd.VaqHipError):
         v.parseMethodString("VAQ128m32min2max4var1,FAST")

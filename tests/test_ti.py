@@ -251,3 +251,30 @@ def test_gpu_ti_state_errors():
     with pytest.raises(_lib.VaqHipError):
         v.search(c["X"], 5, projected=True)
     v.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ti_cpp_demo_driver(tmp_path):
+    """examples/demo_vaqhip.cpp with --method ...,EA_TI<T>m<seg> --visit-cluster: the
+    C++ adapter's TI members (mTIClusters, mVisit, clusterTI) over the C ABI."""
+    import subprocess
+    from vaq_amd import build, io
+    exe = build.build_demo()
+    c = ti_case(250, 128, [8] * 8, 30000, 20, 60, 4)
+    ti = po.cluster_ti(c["codes"], c["cents"], c["clusters"], 4)
+    io.save_centroids(c["cents"], str(tmp_path / "c.bin"))
+    io.save_codebook(c["codes"], str(tmp_path / "cb.bin"))
+    io.write_vecs(str(tmp_path / "q.fvecs"), c["X"])
+    c["clusters"].tofile(str(tmp_path / "ti.f32"))
+    k = 50
+    ol, od, _ = po.search_ti(c["X"], c["cents"], ti, k, visit=0.2, projected=True)
+    r = subprocess.run([exe, "--centroids", str(tmp_path / "c.bin"), "--codebook", str(tmp_path / "cb.bin"),
+                        "--queries", str(tmp_path / "q.fvecs"), "--timeseries-size", "128", "--k", str(k),
+                        "--method", "VAQ64m8min8max8var1,EA_TI60m4", "--visit-cluster", "0.2",
+                        "--ti-clusters", str(tmp_path / "ti.f32"), "--result", str(tmp_path / "out.csv")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.loadtxt(str(tmp_path / "out.csv"), delimiter=",", dtype=np.int64)
+    alld = visited_dists(c, ti, 0.2, k)
+    d_got = np.take_along_axis(alld, got, axis=1).astype(np.float32)
+    assert_topk_matches(got.astype(np.int32), d_got, ol, od, all_dists=alld, what="cpp demo TI")

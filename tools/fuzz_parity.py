@@ -3,6 +3,10 @@
 k, and scan options, each checked against the CPU oracle under the tie contract.
 
     python tools/fuzz_parity.py [seconds] [seed]
+
+Every third index is also regrouped by random triangle-inequality clusters and
+searched with TI|EA / TI at random visit fractions.  A progress line is printed
+every ~20 s (a silent GPU job is taken for hung).
 """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +20,28 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 po.build(ref=False)
-t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0
+t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0; n_ti = 0; t_print = t0
+
+
+def visited_dists(c, ti, T, seg, visit, k, Xp):
+    out = np.full((Xp.shape[0], c["codes"].shape[0]), np.inf, dtype=np.float32)
+    sizes = np.diff(ti["start"])
+    for q in range(Xp.shape[0]):
+        qcc, order = po.ti_query_order(Xp[q, :seg * c["L"]], ti["clusters"])
+        nv = int(np.float32(T) * np.float32(visit)) if visit < 1 else T
+        cum = np.cumsum(sizes[order])
+        enough = int(np.searchsorted(cum, k) + 1) if cum[-1] >= k else T
+        nv = min(T, max(nv, enough))
+        rows = np.concatenate([ti["member"][ti["start"][t]:ti["start"][t + 1]] for t in order[:nv]])
+        lut = po.create_lut(Xp[q], c["cents"], max(c["bits"]))
+        out[q, rows] = np.sqrt(po.all_dists(lut, c["codes"][rows]))
+    return out
+
+
 while time.time() - t0 < budget:
+    if time.time() - t_print > 20:
+        t_print = time.time()
+        print(f"[{t_print - t0:.0f}s] {n_cases} indexes, {n_searches} searches ({n_ti} TI)", flush=True)
     M = int(rng.choice([4, 8, 8, 12, 16, 16, 20, 32, 64]))
     L = int(rng.choice([1, 2, 4, 8, 16]))
     D = M * L
@@ -63,6 +87,40 @@ while time.time() - t0 < budget:
         except AssertionError as e:
             print("MISMATCH", e); print("case seed info:", M, L, bits, N, nq, k, opts); sys.exit(1)
         n_searches += 1
+    if n_cases % 3 == 0 and N >= 64 and M % 4 == 0 and sum(1 << b for b in bits) * 4 < 120000:
+        # triangle-inequality form on the same rows
+        T = int(rng.choice([1, 2, 7, 40, 300]))
+        seg = int(rng.integers(1, M + 1))
+        if seg * L <= 1024:
+            pick = rng.integers(0, N, size=T)
+            cl = np.concatenate([c["cents"][s][c["codes"][pick, s].astype(np.int64)] for s in range(seg)], axis=1)
+            if rng.integers(0, 3) == 0:
+                cl = cl + rng.normal(size=cl.shape).astype(np.float32)
+            cl = np.ascontiguousarray(cl, dtype=np.float32)
+            ti = po.cluster_ti(c["codes"], c["cents"], cl, seg, nthreads=8)
+            v.mTIClusters = cl; v.mTISegmentNum = seg
+            for _ in range(3):
+                visit = float(rng.choice([1.0, 0.5, 0.1, 0.013]))
+                ea = bool(rng.integers(0, 4) != 0)
+                v.mMethods = vaq_amd.NNMethod.TI | (vaq_amd.NNMethod.EA if ea else 0)
+                v.mVisit = visit
+                v.set_option("slices", int(rng.choice([0, 0, 1, 3, 40])))
+                v.set_option("waves_per_workgroup", int(rng.choice([0, 4, 8, 16])))
+                a = v.search(c["X"], k)
+                ol, od, _ = po.search_ti(Xp, c["cents"], ti, k, visit=visit, max_bits=max(bits), ea=ea,
+                                         nthreads=8, projected=True)
+                try:
+                    alld = visited_dists(c, ti, T, seg, visit, k, Xp) if ea else None
+                    if ea:
+                        ties += assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), ol, od,
+                                                    alld, what=f"TI M={M} L={L} bits={bits} N={N} T={T} seg={seg}")
+                    else:  # first k rows of the visiting order: the same rows, whatever their distances tie like
+                        assert np.array_equal(a.distances.reshape(nq, k), od)
+                        assert np.array_equal(np.sort(a.labels.reshape(nq, k), 1), np.sort(ol, 1))
+                except AssertionError as e:
+                    print("MISMATCH (TI)", e)
+                    print("case:", M, L, bits, N, nq, k, "T", T, "seg", seg, "visit", visit, "ea", ea); sys.exit(1)
+                n_searches += 1; n_ti += 1
     v.close(); n_cases += 1
 print("unsupported (EUNSUPPORTED) cases:", globals().get("n_unsupported", 0))
 print(f"fuzz ok: {n_cases} indexes, {n_searches} searches, {ties} boundary-tie queries, {time.time()-t0:.0f}s, seed {seed}")

@@ -83,7 +83,8 @@ struct ScanParams {
   const int *ti_nvisit;   // [nq] clusters visited
   const float *ti_xcc;    // [n_rows] row-to-centre distances (index order)
   int ti_rowcap;          // rows taken from the visiting order (INT_MAX = all)
-  int sqrt_out;           // 1: results carry sqrt(distance) (VAQ.cpp:1583)
+  int sqrt_out;           // 1: the k-min is kept on sqrt(distance), as the reference stores it
+                          //    (VAQ.cpp:1583); partial lists and g_thr then hold square roots
   float *part_d;          // [nq][n_slices][k]
   int *part_id;
 };
@@ -139,8 +140,7 @@ size_t merge_scratch_elems(int n_lists, int nq, int k);
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,
-                        unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st,
-                        int sqrt_out = 0);
+                        unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st);
 
 // ---- triangle-inequality cluster pruning (vaq_ti.hip) ----------------------
 // packed index rows -> uint16 N x M in original row order (inverse of launch_pack_codes)

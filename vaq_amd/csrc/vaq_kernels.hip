@@ -588,6 +588,23 @@ __host__ __device__ inline size_t ti_lds_bytes(int n_clusters) {
 // exact k-min of the visited rows, whatever order the waves ran in.
 constexpr float TI_SLACK = 1.0f / 8192.0f;
 
+// largest x with sqrtf(x) <= t (t >= 0): row sums are compared against it so that the
+// partial-sum tests agree exactly with a comparison of square roots.  fl(t * t) is within
+// half an ulp of t^2 and the answer within ~2 ulps above it.
+__device__ __forceinline__ float sq_bound(float t) {
+  if (!(t < 1.8446742e19f)) return FLT_MAX;  // t * t would overflow (includes the neutral FLT_MAX)
+  float c = t * t;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float n = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) + 1u);
+    if (sqrtf(n) <= t) c = n;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (sqrtf(c) > t && c > 0.0f) c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) - 1u);
+  return c;
+}
+
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
 // LDS: [LUT][QB x selection state][per wave: survivor queue]
@@ -596,6 +613,12 @@ template <int QB> struct ScanCtx {
   LT *lut;
   SelView sel[QB];
   float thr_d[QB];   // wave-uniform cached copy of each query's threshold distance (>= exact)
+  // TI form: the reference stores and compares sqrt(distance) (VAQ.cpp:1583-1587), and sqrt
+  // merges neighbouring floats, so the k-min is kept on (sqrt(dist), label): the selection
+  // state and the shared thresholds hold square roots, thr_s caches the threshold itself and
+  // thr_d the largest row sum whose square root does not exceed it (for the partial-sum tests)
+  bool sq;
+  float thr_s[QB];
   int qi[QB];
   int *q_id;         // survivor queue (wave-private): row id
   float *q_p;        // [QB][qcap]: sum of the row's first group of four subspaces
@@ -704,6 +727,7 @@ template <int QB> struct ScanCtx {
     qcap = p.qcap;
     qcnt = 0;
     multi_slice = p.share_thr != 0;
+    sq = p.sqrt_out != 0;
     g_thr = p.g_thr;
     perm = p.perm;
     lut = reinterpret_cast<LT *>(smem);
@@ -715,6 +739,7 @@ template <int QB> struct ScanCtx {
       qi[q] = x < p.nq ? x : p.nq - 1;
       sel[q] = sel_view(smem + off + (size_t)q * sb, p.kp, p.ccap);
       thr_d[q] = FLT_MAX;
+      thr_s[q] = FLT_MAX;
       for (int i = tid; i < p.kp; i += nthreads) {
         sel[q].d[i] = INFINITY;
         sel[q].id[i] = ID_SENTINEL;
@@ -854,8 +879,19 @@ template <int QB> struct ScanCtx {
           t = g;
         }
       }
-      thr_d[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)t));
+      set_thr(q, bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)t)));
     }
+  }
+
+  // cache a (wave-uniform) threshold read from the selection state
+  __device__ __forceinline__ void set_thr(int q, float t) {
+    if (!sq) {
+      thr_d[q] = t;
+      return;
+    }
+    if (t == thr_s[q]) return;
+    thr_s[q] = t;
+    thr_d[q] = sq_bound(t);
   }
 
   // true unless the partial sums rule the row out for every query of the
@@ -878,8 +914,8 @@ template <int QB> struct ScanCtx {
     const int rid = (ok && survives(dist) && perm) ? (int)perm[srow] : srow;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
-      const float dq = dist[q];
-      if (__ballot(ok && !(dq > thr_d[q])) == 0ull) continue;
+      if (__ballot(ok && !(dist[q] > thr_d[q])) == 0ull) continue;
+      const float dq = sq ? sqrtf(dist[q]) : dist[q];
       const SelView &v = sel[q];
       sel_lock(v, lane);
       float td = bits_to_float(v.hdr[SEL_THR_D]);
@@ -909,7 +945,7 @@ template <int QB> struct ScanCtx {
         }
       }
       sel_unlock(v, lane);
-      thr_d[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(td)));
+      set_thr(q, bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(td))));
     }
   }
 
@@ -946,7 +982,7 @@ template <int QB> struct ScanCtx {
             const int id = sel[q].id[i];
             const bool ok = id != ID_SENTINEL;
             p.final_labels[o + i] = ok ? (int32_t)(id + p.id_base) : -1;
-            p.final_dist[o + i] = ok ? (p.sqrt_out ? sqrtf(sel[q].d[i]) : sel[q].d[i]) : FLT_MAX;
+            p.final_dist[o + i] = ok ? sel[q].d[i] : FLT_MAX;
           }
         } else {
           const size_t o = ((size_t)x * p.n_slices + slice) * k;
@@ -1243,7 +1279,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 // the bound qc - xcc only grows from here on: once it clears the threshold the
                 // rest of the unit cannot hold an admissible row
                 const float bound = (qc - xcur) - TI_SLACK * (qc + xcur);
-                if (bound >= sqrtf(cx.thr_d[0])) break;
+                if (bound >= cx.thr_s[0]) break;
               }
               const int row0 = base + lane * Item::ROWS;
               // A: dism = l0; dism += l1, every row of the item, all lanes
@@ -1575,7 +1611,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
               cx.refresh(stepno++);
               if (TI) {  // VAQ.cpp:1564-1568, see scan_bytes_body
                 const float bound = (qc - xcur) - TI_SLACK * (qc + xcur);
-                if (bound >= sqrtf(cx.thr_d[0])) break;
+                if (bound >= cx.thr_s[0]) break;
               }
               const int row = base + lane;
               const uint32_t w0w = cur.w[0];
@@ -1872,7 +1908,6 @@ constexpr int MERGE_FANIN = 16;  // lists folded by one workgroup (16 x k <= 204
 
 // grid = (query, group); group g folds lists [g*lists_per_group, ...).
 //  final != 0 : write labels (+id_base) / distances with -1 / FLT_MAX in empty slots
-//               (final == 2: distances as sqrt, the TI form's convention, VAQ.cpp:1583)
 //  final == 0 : write the group's k best as an intermediate list (raw ids, sentinels kept)
 //  thr_out    : optional [nq] float bits; receives min(thr_out[q], k-th distance) when k rows exist
 __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
@@ -1918,7 +1953,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_kernel(
     const bool ok = i < kept && si[i] != ID_SENTINEL;
     if (final) {
       out_id[o + i] = ok ? (int32_t)(si[i] + id_base) : -1;
-      out_d[o + i] = ok ? (final == 2 ? sqrtf(sd[i]) : sd[i]) : FLT_MAX;
+      out_d[o + i] = ok ? sd[i] : FLT_MAX;
     } else {
       out_id[o + i] = ok ? si[i] : ID_SENTINEL;
       out_d[o + i] = ok ? sd[i] : INFINITY;
@@ -2063,7 +2098,7 @@ size_t merge_scratch_elems(int n_lists, int nq, int k) {
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k, int64_t id_base,
                         int in_final, int32_t *labels, float *dist, unsigned *thr_out,
-                        float *scratch_d, int *scratch_id, hipStream_t st, int sqrt_out) {
+                        float *scratch_d, int *scratch_id, hipStream_t st) {
   if (nq == 0 || k == 0) return hipSuccess;
   const float *cur_d = part_d;
   const int *cur_id = part_id;
@@ -2107,7 +2142,7 @@ hipError_t launch_merge(const float *part_d, const int *part_id, const int *part
   }
   hipLaunchKernelGGL(merge_kernel, dim3(nq, 1), dim3(MERGE_THREADS), 0, st, cur_d, cur_id, n_lists,
                      n_lists > 0 ? n_lists : 1, list_stride, query_stride, k, id_base, in_final,
-                     labels ? (sqrt_out ? 2 : 1) : 0, labels ? labels : si, labels ? dist : sd, thr_out);
+                     labels ? 1 : 0, labels ? labels : si, labels ? dist : sd, thr_out);
   return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 // add unfused, or its SSE orders for d in {1,2,4,8,12} (:38-128).
 #include "vaq_kernels.h"
 
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -109,34 +110,37 @@ __device__ __forceinline__ float l2sqr_ref_order(const float *xs, int xstride, c
 // ---------------------------------------------------------------------------
 __global__ void ti_assign_kernel(const uint16_t *__restrict__ codes, int64_t n, int M, int L, int seg,
                                  const SubDesc *__restrict__ sub, const float *__restrict__ cent,
-                                 const float *__restrict__ clusters, int T, int *__restrict__ assign,
-                                 float *__restrict__ xcc) {
-  extern __shared__ float xs[];  // [d][R]
+                                 const float *__restrict__ clusters, int T, float *__restrict__ scratch,
+                                 int *__restrict__ assign, float *__restrict__ xcc) {
+  extern __shared__ float xs_lds[];  // [d][R]
   const int R = blockDim.x;
   const int d = seg * L;
-  const int64_t r = (int64_t)blockIdx.x * R + threadIdx.x;
-  if (r < n) {
+  // centres of more dims than LDS holds for 64 rows: the decoded rows live in a global
+  // scratch tile per workgroup instead (same [dim][row] shape, each thread its own column)
+  float *xs = scratch ? scratch + (size_t)blockIdx.x * d * R : xs_lds;
+  for (int64_t blk = blockIdx.x; blk * R < n; blk += gridDim.x) {
+    const int64_t r = blk * R + threadIdx.x;
+    if (r >= n) continue;
     for (int s = 0; s < seg; s++) {
       const SubDesc sd = sub[s];
       const float *c = cent + sd.cent_off + (size_t)(codes[r * M + s] & (sd.ncent - 1)) * L;
       for (int j = 0; j < L; j++) xs[(s * L + j) * R + threadIdx.x] = c[j];
     }
-  }
-  // each thread reads back only its own column: no barrier needed
-  if (r >= n) return;
-  float closest = FLT_MAX;
-  int idx = 0;  // (the reference would index [-1] if no distance were < FLT_MAX)
-  bool found = false;
-  for (int c = 0; c < T; c++) {
-    const float dist = sqrtf(l2sqr_ref_order(xs + threadIdx.x, R, clusters + (size_t)c * d, d));
-    if (dist < closest) {
-      closest = dist;
-      idx = c;
-      found = true;
+    // each thread reads back only its own column: no barrier needed
+    float closest = FLT_MAX;
+    int idx = 0;  // (the reference would index [-1] if no distance were < FLT_MAX)
+    bool found = false;
+    for (int c = 0; c < T; c++) {
+      const float dist = sqrtf(l2sqr_ref_order(xs + threadIdx.x, R, clusters + (size_t)c * d, d));
+      if (dist < closest) {
+        closest = dist;
+        idx = c;
+        found = true;
+      }
     }
+    assign[r] = idx;
+    xcc[r] = found ? closest : FLT_MAX;
   }
-  assign[r] = idx;
-  xcc[r] = found ? closest : FLT_MAX;
 }
 
 // key = cluster << 32 | ~bits(xcc): ascending key order = cluster ascending, xcc
@@ -160,11 +164,13 @@ __global__ void ti_bounds_kernel(const uint64_t *__restrict__ keys, int64_t n, i
   xcc_sorted[i] = __builtin_bit_cast(float, ~(unsigned)(keys[i] & 0xffffffffu));
 }
 
-size_t ti_assign_lds(int d, int *rows_out) {
+// rows per workgroup and its LDS bytes; 0 bytes = the tile does not fit LDS (global scratch)
+static size_t ti_assign_lds(int d, int *rows_out) {
   int R = 256;
   while (R > 64 && (size_t)R * d * 4 > 48 * 1024) R >>= 1;
   if (rows_out) *rows_out = R;
-  return (size_t)R * d * 4;
+  const size_t bytes = (size_t)R * d * 4;
+  return bytes <= 128 * 1024 ? bytes : 0;
 }
 
 // Regroup: d_perm[n] (index row -> original row), d_start[T+1] (first index row
@@ -176,13 +182,13 @@ hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int s
   hipError_t e = hipMemsetAsync(d_start, 0xff, (size_t)(T + 1) * sizeof(int), st);
   if (e != hipSuccess || n == 0) return e;
   int *assign = nullptr;
-  float *xcc = nullptr;
+  float *xcc = nullptr, *scratch = nullptr;
   uint64_t *keys_in = nullptr, *keys_out = nullptr;
   uint32_t *idx_in = nullptr;
   void *temp = nullptr;
   size_t temp_bytes = 0;
   auto cleanup = [&]() {
-    (void)hipFree(assign); (void)hipFree(xcc); (void)hipFree(keys_in); (void)hipFree(keys_out);
+    (void)hipFree(assign); (void)hipFree(xcc); (void)hipFree(scratch); (void)hipFree(keys_in); (void)hipFree(keys_out);
     (void)hipFree(idx_in); (void)hipFree(temp);
   };
   if ((e = hipMalloc(&assign, (size_t)n * 4)) != hipSuccess || (e = hipMalloc(&xcc, (size_t)n * 4)) != hipSuccess ||
@@ -194,11 +200,18 @@ hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int s
   }
   int R = 0;
   const size_t lds = ti_assign_lds(seg * L, &R);
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_assign_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int64_t grid = (n + R - 1) / R;
+  if (lds == 0) {
+    grid = std::min<int64_t>(grid, 2048);
+    e = hipMalloc(&scratch, (size_t)grid * R * seg * L * sizeof(float));
+  } else {
+    grid = std::min<int64_t>(grid, (int64_t)1 << 30);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(ti_assign_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(ti_assign_kernel, dim3((unsigned)((n + R - 1) / R)), dim3(R), lds, st, d_codes, n, M,
-                       L, seg, sub, cent, d_clusters, T, assign, xcc);
+    hipLaunchKernelGGL(ti_assign_kernel, dim3((unsigned)grid), dim3(R), lds, st, d_codes, n, M, L, seg, sub,
+                       cent, d_clusters, T, scratch, assign, xcc);
     e = hipGetLastError();
   }
   const unsigned blocks = (unsigned)((n + 255) / 256);

@@ -428,7 +428,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
         HIP_TRY(vaq::launch_merge(sp.part_d, sp.part_id, nullptr, ix->N > 0 ? pl.n_slices : 0, k,
                                   (int64_t)pl.n_slices * k, n, k, ix->id_base, 0,
                                   d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, nullptr,
-                                  ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st, 1));
+                                  ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
       if (timing) HIP_TRY(hipEventRecord(ev[5], st));
       tm.seed_slices = 0;
       tm.queries_per_pass = 1;
