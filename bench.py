@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--order", type=int, default=0, help="best-first slice order on/off (experimental)")
     ap.add_argument("--seed-frac", type=int, default=0, help="pre-pass scans N / this many rows (0 = default 64)")
     ap.add_argument("--hot", type=int, default=-1, help="best-first buckets per workgroup (0..32, -1 = default)")
+    ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
+                                             "seg subspaces (default all), method EA_TI (not the headline metric)")
+    ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -164,6 +167,26 @@ def main():
         for r in range(0, n_local, step_rows):
             m = min(step_rows, n_local - r)
             codes[r: r + m] = torch.randint(0, 256, (m, M), generator=g, device=dev, dtype=torch.int16)
+    ti_T = ti_seg = 0
+    if args.ti:
+        # VAQ::clusterTI: centres = k-means over decoded code rows (at most 256 per centre, as
+        # KMeans::staticFitCodebook samples, KMeans.hpp:618-650); training, so it runs in the harness
+        parts = [int(x) for x in args.ti.split(",")]
+        ti_T, ti_seg = parts[0], (parts[1] if len(parts) > 1 else M)
+        g = torch.Generator(device="cpu").manual_seed(harness.SEED)
+        pick = torch.randperm(n_local, generator=g)[: min(n_local, 256 * ti_T)].to(dev)
+        samp = codes[pick].to(torch.int64) & 0xffff
+        L = D // M
+        dec = torch.cat([torch.from_numpy(cents[s]).to(dev)[samp[:, s]] for s in range(ti_seg)], dim=1)
+        cl = harness.kmeans(dec, ti_T, iters=25, seed=harness.SEED)
+        if world > 1:
+            dist.broadcast(cl, 0)
+        v.mTIClusters = cl.cpu().numpy()
+        v.mTISegmentNum = ti_seg
+        v.mTIClusterNum = ti_T
+        v.mMethods = vaq_amd.NNMethod.TI | vaq_amd.NNMethod.EA
+        v.mVisit = args.visit
+        del dec, samp, pick
     v.mCodebook = codes
     v._ensure_codes()
     host_codes = None
@@ -266,7 +289,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-        "kernel": "scan_%s_kernel" % ("bytes" if info["layout"] == 0 else "bits"),
+        "kernel": "scan_%s%s_kernel" % ("bytes" if info["layout"] == 0 else "bits", "_ti" if args.ti else ""),
         "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
         "queries_per_pass": tm["queries_per_pass"], "passes": tm["passes"],
         "algorithmic_bytes_per_launch": algo_bytes,
@@ -282,7 +305,8 @@ def main():
     # profiles/ and attached here when it matches the workload and plan.
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
-        if tr and world == 1 and not args.rows and not args.nq and tm["queries_per_pass"] == tr["queries_per_pass"]:
+        if tr and world == 1 and not args.rows and not args.nq and not args.ti \
+                and tm["queries_per_pass"] == tr["queries_per_pass"]:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
     except (OSError, ValueError):
@@ -310,20 +334,32 @@ def main():
         qh = queries.cpu().numpy()
         eig_h = v.mEigenVectors
         n_rows_cpu = host_codes.shape[0]
+        if args.ti:
+            # the same method on the CPU: VAQ::clusterTI + searchTriangleInequality restated
+            t1 = time.perf_counter()
+            ti_h = po.cluster_ti(host_codes, cents, v.mTIClusters, ti_seg, nthreads=threads)
+            log(f"[cpu] clusterTI restatement {time.perf_counter() - t1:.1f}s")
+
+            def cpu_search(X, nthreads):
+                l_, d_, _ = po.search_ti(X, cents, ti_h, k, visit=args.visit, eig=eig_h, nthreads=nthreads)
+                return l_, d_
+        else:
+            def cpu_search(X, nthreads):
+                return po.search(X, cents, host_codes, k, eig=eig_h, nthreads=nthreads)
         # calibrate on `threads` queries, then size the sample for ~cpu_seconds
         t1 = time.perf_counter()
-        po.search(qh[:threads], cents, host_codes, k, eig=eig_h, nthreads=threads)
+        cpu_search(qh[:threads], threads)
         per_round = max(1e-3, time.perf_counter() - t1)
         n_cpu = int(min(nq, max(threads, threads * (args.cpu_seconds / per_round))))
         t1 = time.perf_counter()
-        cl, cd = po.search(qh[:n_cpu], cents, host_codes, k, eig=eig_h, nthreads=threads)
+        cl, cd = cpu_search(qh[:n_cpu], threads)
         dt = time.perf_counter() - t1
         scale = n_rows_cpu / float(N)  # rows scanned per query relative to the full job
         cpu_qps = n_cpu / dt * scale
         # single thread = the reference's execution model (VAQ.cpp:786)
         n1 = max(1, min(n_cpu, int(3.0 / (per_round)) + 1))
         t1 = time.perf_counter()
-        po.search(qh[:n1], cents, host_codes, k, eig=eig_h, nthreads=1)
+        cpu_search(qh[:n1], 1)
         dt1 = time.perf_counter() - t1
         cpu = {
             "value": round(cpu_qps, 2), "unit": "queries/s", "cores": threads, "kind": "port",
@@ -332,7 +368,17 @@ def main():
                       + ("" if scale == 1.0 else f", scaled x{scale:.4g} to {N} rows"),
             "single_thread_qps": round(n1 / dt1 * scale, 2),
         }
-        if world == 1 and n_rows_cpu == n_local:
+        if world == 1 and n_rows_cpu == n_local and args.ti:
+            # distances must agree exactly; labels may differ only inside runs of equal distance
+            chk = min(n_cpu, 32)
+            gd = dists_[:chk].cpu().numpy()
+            assert np.array_equal(gd, cd[:chk]), "bench parity (TI): distances differ"
+            gl = labels[:chk].cpu().numpy()
+            for q in range(chk):
+                for dv in np.unique(gd[q][:-1][gd[q][:-1] != gd[q][-1]]):
+                    assert set(gl[q][gd[q] == dv]) == set(cl[q][cd[q] == dv]), "bench parity (TI): labels differ"
+            cpu["parity_checked_queries"] = chk
+        elif world == 1 and n_rows_cpu == n_local:
             # same inputs: the CPU port is also the parity checker for the bench's own result
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from helpers import assert_topk_matches
@@ -352,6 +398,8 @@ def main():
             "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq, "k": k,
                        "bits": bits, "code_bytes": info["algo_code_bytes"],
                        "codes": "encoded" if real_codes else "uniform-random",
+                       "method": ("EA_TI%dm%d visit=%g (k-means centres over decoded codes)" % (ti_T, ti_seg, args.visit))
+                       if args.ti else "HEAP/EA (exhaustive)",
                        "sharding": "none" if world == 1 else (
                            "rows: contiguous shards, RCCL all-gather of per-shard top-k + merge" if mode == "rows"
                            else "queries: codes replicated (fit HBM), disjoint query slices, RCCL all-gather of results")},

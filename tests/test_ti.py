@@ -181,6 +181,23 @@ def test_gpu_ti_without_ea_matches_oracle(cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ea", [True, False])
+def test_gpu_ti_long_visiting_list_is_staged_in_chunks(ea):
+    """visit asks for 10 clusters (the kernel stages 64 list entries at a time) but k = 1000
+    rows need ~70 of these 15-row clusters: the until-k-rows rule (VAQ.cpp:1555, :1611)."""
+    from vaq_amd.index import NNMethod
+    seed, D, bits, N, nq, T, seg = TI_CONFIGS[3]
+    c = ti_case(seed, D, bits, N, nq, T, seg)
+    ti = po.cluster_ti(c["codes"], c["cents"], c["clusters"], seg)
+    v = _gpu_index(c, methods=NNMethod.TI | (NNMethod.EA if ea else 0), visit=0.05)
+    k = 1000
+    ans = v.search(c["X"], k, projected=True)
+    ol, od, _ = po.search_ti(c["X"], c["cents"], ti, k, visit=0.05, ea=ea, projected=True)
+    assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), ol, od, what=f"chunks ea={ea}")
+    v.close()
+
+
+@pytest.mark.gpu
 def test_gpu_ti_regroup_after_codes_and_back():
     """clusterTI after encode (the reference's call order), then back to HEAP."""
     from vaq_amd.index import NNMethod

@@ -83,6 +83,7 @@ struct ScanParams {
   const int *ti_nvisit;   // [nq] clusters visited
   const float *ti_xcc;    // [n_rows] row-to-centre distances (index order)
   int ti_rowcap;          // rows taken from the visiting order (INT_MAX = all)
+  int ti_cap;             // entries of the visiting list a workgroup stages in LDS at a time
   int sqrt_out;           // 1: the k-min is kept on sqrt(distance), as the reference stores it
                           //    (VAQ.cpp:1583); partial lists and g_thr then hold square roots
   float *part_d;          // [nq][n_slices][k]
@@ -155,8 +156,8 @@ hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int s
 hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters, int T,
                           const int *start, int max_visit, int k, int *order, float *qcc, int *nvisit,
                           hipStream_t st);
-// extra LDS bytes of a TI scan workgroup
-size_t scan_ti_lds_bytes(int n_clusters);
+// extra LDS bytes of a TI scan workgroup staging `cap` entries of its visiting list
+size_t scan_ti_lds_bytes(int cap);
 
 } // namespace vaq
 #endif

@@ -577,9 +577,9 @@ constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
 constexpr int HOT_SEG_STEPS = VAQ_HOT_SEG;  // wave steps per best-first work unit
 constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
 
-// TI form: begin / end / centre distance per visited cluster + unit prefix
+// TI form: begin / end / centre distance / farthest member per visited cluster + unit prefix
 __host__ __device__ inline size_t ti_lds_bytes(int n_clusters) {
-  return ((size_t)n_clusters * 16 + 4 + 15) & ~(size_t)15;
+  return ((size_t)n_clusters * 20 + 4 + 15) & ~(size_t)15;
 }
 // Slack of the TI bound: the reference prunes when bsfK <= qToCCDist - mCodeToCCDist
 // (VAQ.cpp:1566); both distances and the row sums carry fp32 rounding (a few ulp per
@@ -608,7 +608,7 @@ __device__ __forceinline__ float sq_bound(float t) {
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
 // LDS: [LUT][QB x selection state][per wave: survivor queue]
-template <int QB> struct ScanCtx {
+template <int QB, bool SQ> struct ScanCtx {
   typedef typename LutVec<QB>::T LT;
   LT *lut;
   SelView sel[QB];
@@ -617,7 +617,7 @@ template <int QB> struct ScanCtx {
   // merges neighbouring floats, so the k-min is kept on (sqrt(dist), label): the selection
   // state and the shared thresholds hold square roots, thr_s caches the threshold itself and
   // thr_d the largest row sum whose square root does not exceed it (for the partial-sum tests)
-  bool sq;
+  static constexpr bool sq = SQ;  // (the TI kernels)
   float thr_s[QB];
   int qi[QB];
   int *q_id;         // survivor queue (wave-private): row id
@@ -642,8 +642,10 @@ template <int QB> struct ScanCtx {
   int *ti_begin;       // [nv] first index row of the i-th visited cluster
   int *ti_end;         // [nv] one past the last row taken from it
   float *ti_q;         // [nv] query-to-centre distance (qToCCDist)
+  float *ti_x0;        // [nv] centre distance of the cluster's first (= farthest) row taken
   int *ti_pre;         // [nv + 1] prefix of work-unit counts
-  int ti_nv;
+  int ti_nv;           // entries staged (one chunk of at most ti_cap of the visiting list)
+  int ti_rows_before;  // rows of the clusters visited in earlier chunks (wave 0 keeps it)
 
   // Rank the buckets of the slice [r0, r1) by key = min over the batch's queries of
   // the first LUT term and keep the n_hot best.  Uses the (not yet staged) LUT
@@ -727,7 +729,6 @@ template <int QB> struct ScanCtx {
     qcap = p.qcap;
     qcnt = 0;
     multi_slice = p.share_thr != 0;
-    sq = p.sqrt_out != 0;
     g_thr = p.g_thr;
     perm = p.perm;
     lut = reinterpret_cast<LT *>(smem);
@@ -769,12 +770,14 @@ template <int QB> struct ScanCtx {
     hot_ticket = hot_mask + HOT_MASK_WORDS;
     off += HOT_BYTES;
     ti_nv = 0;
+    ti_rows_before = 0;
     if (p.ti) {
       ti_begin = reinterpret_cast<int *>(smem + off);
-      ti_end = ti_begin + p.n_buckets;
-      ti_q = reinterpret_cast<float *>(ti_end + p.n_buckets);
-      ti_pre = reinterpret_cast<int *>(ti_q + p.n_buckets);
-      off += ti_lds_bytes(p.n_buckets);
+      ti_end = ti_begin + p.ti_cap;
+      ti_q = reinterpret_cast<float *>(ti_end + p.ti_cap);
+      ti_x0 = ti_q + p.ti_cap;
+      ti_pre = reinterpret_cast<int *>(ti_x0 + p.ti_cap);
+      off += ti_lds_bytes(p.ti_cap);
     }
     const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
     unsigned char *qb = smem + off + (size_t)wave * q_bytes;
@@ -784,22 +787,27 @@ template <int QB> struct ScanCtx {
 
   // TI form (VAQ::searchTriangleInequality, VAQ.cpp:1548-1560): the clusters this query
   // visits, in order, with the rows taken from each (all of them, or what is left of the
-  // row budget) cut into work units of seg_rows rows aligned to the wave step.
-  __device__ __forceinline__ void stage_ti(const ScanParams &p, int seg_rows, int wstep, int tid,
+  // row budget) cut into work units of seg_rows rows aligned to the wave step.  The list is
+  // staged ti_cap entries at a time starting at entry c0 (one chunk is the normal case: the
+  // host sizes ti_cap for int(T * visit); only the until-k-rows rule can make it longer).
+  __device__ __forceinline__ void stage_ti(const ScanParams &p, int c0, int seg_rows, int wstep, int tid,
                                            int nthreads) {
     const int T = p.n_buckets;
     const int q = qi[0];
-    const int nv = p.ti_nvisit[q];
+    int nv = p.ti_nvisit[q] - c0;
+    if (nv > p.ti_cap) nv = p.ti_cap;
     ti_nv = nv;
     for (int i = tid; i < nv; i += nthreads) {
-      const int c = p.ti_order[(size_t)q * T + i];
-      ti_begin[i] = p.bucket_start[c];
-      ti_end[i] = p.bucket_start[c + 1];
-      ti_q[i] = p.ti_qcc[(size_t)q * T + i];
+      const int c = p.ti_order[(size_t)q * T + c0 + i];
+      const int b = p.bucket_start[c], e = p.bucket_start[c + 1];
+      ti_begin[i] = b;
+      ti_end[i] = e;
+      ti_q[i] = p.ti_qcc[(size_t)q * T + c0 + i];
+      ti_x0[i] = e > b ? p.ti_xcc[b] : 0.0f;
     }
     __syncthreads();
     if (wave == 0) {
-      int carry_rows = 0, carry_units = 0;
+      int carry_rows = ti_rows_before, carry_units = 0;
       for (int base = 0; base < nv; base += 64) {
         const int i = base + lane;
         const int b = i < nv ? ti_begin[i] : 0;
@@ -828,6 +836,7 @@ template <int QB> struct ScanCtx {
         carry_rows += __builtin_amdgcn_readlane(inc, 63);
         carry_units += __builtin_amdgcn_readlane(uinc, 63);
       }
+      ti_rows_before = carry_rows;
       if (lane == 0) {
         ti_pre[nv] = carry_units;
         *hot_ticket = 0u;
@@ -1065,11 +1074,11 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
 
-  ScanCtx<QB> cx;
+  ScanCtx<QB, TI> cx;
   cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
   if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
-  if (TI) cx.stage_ti(p, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
+  if (TI) cx.stage_ti(p, 0, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
   cx.stage_lut(p, M * 256, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave;
@@ -1167,8 +1176,9 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     // natural order (minus the buckets already done)
     bool hot_phase = !TI && cx.n_hot > 0;
     const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
-    const int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
-    int ti_cur = 0;
+    int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
+    const int ti_all = TI ? p.ti_nvisit[cx.qi[0]] : 0;
+    int ti_cur = 0, ti_c0 = 0;
     const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
     if (!TI && w0 < w1) {
@@ -1190,7 +1200,16 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
         if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         const int64_t u64 = (int64_t)t * p.n_slices + slice;
-        if (u64 >= ti_total) break;
+        if (u64 >= ti_total) {
+          // this chunk of the visiting list is done; every wave gets here once per chunk
+          if (ti_c0 + p.ti_cap >= ti_all) break;
+          __syncthreads();
+          ti_c0 += p.ti_cap;
+          cx.stage_ti(p, ti_c0, SEG_ROWS, WSTEP, tid, nthreads);
+          ti_total = cx.ti_pre[cx.ti_nv];
+          ti_cur = 0;
+          continue;
+        }
         const int u = (int)u64;
         int lo = ti_cur, hi = cx.ti_nv;  // largest i with ti_pre[i] <= u
         while (hi - lo > 1) {
@@ -1200,6 +1219,9 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
         ti_cur = lo;
         const int bs = cx.ti_begin[lo], bend = cx.ti_end[lo];
         qc = cx.ti_q[lo];
+        // the whole cluster is out of reach (its farthest member gives the smallest bound):
+        // decided from LDS, without touching the unit's rows or their centre distances
+        if ((qc - cx.ti_x0[lo]) - TI_SLACK * (qc + cx.ti_x0[lo]) >= cx.thr_s[0]) continue;
         const int al = bs & ~(WSTEP - 1);
         const int j = u - cx.ti_pre[lo];
         pos = al + j * SEG_ROWS;
@@ -1365,11 +1387,11 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
 
-  ScanCtx<QB> cx;
+  ScanCtx<QB, TI> cx;
   cx.setup(smem, p, p.lut_lds_entries, qbatch, tid, nthreads);
   if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
-  if (TI) cx.stage_ti(p, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
+  if (TI) cx.stage_ti(p, 0, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
   cx.stage_lut(p, p.lut_lds_entries, tid, nthreads);
   const LT *lut = cx.lut;
   const int lane = cx.lane, wave = cx.wave, nwaves = cx.nwaves;
@@ -1506,8 +1528,9 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
     constexpr int SEG_ROWS = HOT_SEG_STEPS * WSTEP;
     bool hot_phase = !TI && cx.n_hot > 0;
     const int hot_total = hot_phase ? cx.hot_pre[HOT_MAX] : 0;
-    const int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
-    int ti_cur = 0;
+    int ti_total = TI ? cx.ti_pre[cx.ti_nv] : 0;
+    const int ti_all = TI ? p.ti_nvisit[cx.qi[0]] : 0;
+    int ti_cur = 0, ti_c0 = 0;
     const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
     if (!TI && w0 < w1) {
@@ -1526,7 +1549,16 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
         if (lane == 0) t = (int)atomicAdd(cx.hot_ticket, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         const int64_t u64 = (int64_t)t * p.n_slices + slice;
-        if (u64 >= ti_total) break;
+        if (u64 >= ti_total) {
+          // this chunk of the visiting list is done; every wave gets here once per chunk
+          if (ti_c0 + p.ti_cap >= ti_all) break;
+          __syncthreads();
+          ti_c0 += p.ti_cap;
+          cx.stage_ti(p, ti_c0, SEG_ROWS, WSTEP, tid, nthreads);
+          ti_total = cx.ti_pre[cx.ti_nv];
+          ti_cur = 0;
+          continue;
+        }
         const int u = (int)u64;
         int lo = ti_cur, hi = cx.ti_nv;
         while (hi - lo > 1) {
@@ -1536,6 +1568,9 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
         ti_cur = lo;
         const int bs = cx.ti_begin[lo], bend = cx.ti_end[lo];
         qc = cx.ti_q[lo];
+        // the whole cluster is out of reach (its farthest member gives the smallest bound):
+        // decided from LDS, without touching the unit's rows or their centre distances
+        if ((qc - cx.ti_x0[lo]) - TI_SLACK * (qc + cx.ti_x0[lo]) >= cx.thr_s[0]) continue;
         const int al = bs & ~(WSTEP - 1);
         const int j = u - cx.ti_pre[lo];
         pos = al + j * SEG_ROWS;
@@ -1840,8 +1875,10 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
                               p.bucket_shift);
   if (p.ti) {
-    if (p.qb != 1 || p.ea != EA_QUEUE || p.bucket_shift != 0 || p.n_hot != 0) return hipErrorInvalidValue;
-    lds += ti_lds_bytes(p.n_buckets);
+    if (p.qb != 1 || p.ea != EA_QUEUE || p.bucket_shift != 0 || p.n_hot != 0 || !p.sqrt_out)
+      return hipErrorInvalidValue;
+    if (p.ti_cap < 1 || p.ti_cap > p.n_buckets) return hipErrorInvalidValue;
+    lds += ti_lds_bytes(p.ti_cap);
     if (p.layout == LAYOUT_BYTES) {
       switch (p.M) {
       case 8:  return launch_scan_kernel(scan_bytes_ti_kernel<8>, p, lds, grid, st);
@@ -1862,6 +1899,7 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
     default: return hipErrorInvalidValue;
     }
   }
+  if (p.sqrt_out) return hipErrorInvalidValue;  // only the TI kernels select on square roots
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_DISPATCH_QB(scan_bytes, 8)

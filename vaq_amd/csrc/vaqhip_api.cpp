@@ -116,6 +116,7 @@ struct DeviceGuard {
 struct Plan {
   int qb, ea, kp, ccap, qcap, nwaves, n_slices;
   int lds_subs, lut_lds_entries;  // LUT tables staged in LDS (a prefix of the subspaces)
+  int ti_cap = 0;                 // TI form: visiting-list entries staged at a time
   int64_t slice_rows;
   size_t lds;
   // sampling pre-pass that seeds the shared thresholds (0 slices = none)
@@ -232,7 +233,11 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
 // query's work units spread over `n_slices` workgroups when there are few queries.
 int make_ti_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   const int qb = 1, ea = vaq::EA_QUEUE;
-  const size_t ti_bytes = vaq::scan_ti_lds_bytes(ix->ti_T);
+  // the visiting list is int(T * visit) clusters long unless the until-k-rows rule extends it:
+  // stage that many (rounded up to a wave's worth) at a time; longer lists go in chunks
+  const int max_visit = ix->ti_visit < 1.0f ? (int)((float)ix->ti_T * ix->ti_visit) : ix->ti_T;
+  pl->ti_cap = std::min(ix->ti_T, std::max(64, ((max_visit + 63) / 64) * 64));
+  const size_t ti_bytes = vaq::scan_ti_lds_bytes(pl->ti_cap);
   const int need = ix->layout == vaq::LAYOUT_BYTES ? ix->M : 1;
   int best_nw = 0, best_waves = 0, subs = ix->M, entries = ix->lut_floats;
   for (subs = ix->M; subs >= need; subs--) {
@@ -392,6 +397,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.ti_nvisit = nullptr;
     sp.ti_xcc = nullptr;
     sp.ti_rowcap = 0x7fffffff;
+    sp.ti_cap = 0;
     sp.sqrt_out = 0;
     int grid = 0;
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
@@ -412,6 +418,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       // without EA the reference never admits a row after the first k of the visiting order
       // (bsfKSquared stays 0, VAQ.cpp:1617-1686): reproduce that by taking only those rows
       sp.ti_rowcap = (ix->methods & VAQHIP_METHOD_EA) ? 0x7fffffff : k;
+      sp.ti_cap = pl.ti_cap;
       sp.sqrt_out = 1;
       sp.n_slices = pl.n_slices;
       sp.slice_rows = 0;
