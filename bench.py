@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
                                              "seg subspaces (default all), method EA_TI (not the headline metric)")
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
+    ap.add_argument("--bucket-bits", type=int, default=0, help="bits of the first code that key the row buckets (0 = auto)")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -187,6 +188,9 @@ def main():
         v.mMethods = vaq_amd.NNMethod.TI | vaq_amd.NNMethod.EA
         v.mVisit = args.visit
         del dec, samp, pick
+    if args.bucket_bits:
+        v._ensure_index()
+        v.set_option("bucket_bits", args.bucket_bits)
     v.mCodebook = codes
     v._ensure_codes()
     host_codes = None

@@ -256,6 +256,31 @@ def test_cpp_demo_driver(vaqlib, oracle, tmp_path):
     assert "recall@100: 1" in r.stdout
 
 
+@pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[4], CONFIGS[5], CONFIGS[6], CONFIGS[10]],
+                         ids=lambda c: str(c[0]))
+@pytest.mark.parametrize("bucket_bits", [1, 9, 10, 12])
+def test_bucket_key_width(vaqlib, oracle, cfg, bucket_bits):
+    """The bucketed row order keys on the top `bucket_bits` bits of the first code and, once
+    that is used up, of the second (automatic only for >= 16M rows; forced here).  Results do
+    not depend on it."""
+    seed, D, bits, N, nq, k, kw = cfg
+    c = make_case(seed, D, bits, N, nq, **kw)
+    v = make_index(c)
+    v._ensure_index()
+    v.set_option("bucket_bits", bucket_bits)
+    Xp = oracle.project(c["X"], c["eig"]) if c["eig"] is not None else c["X"]
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True)
+    ad = oracle_all_dists(oracle, c, Xp)
+    for qb, slices, ea, hot in [(1, 0, 1, 16), (2, 3, 1, 32), (4, 1, 2, 0), (2, 0, 2, 16), (1, 2, 0, 16)]:
+        v.set_option("queries_per_pass", qb)
+        v.set_option("slices", slices)
+        v.set_option("early_abandon", ea)
+        v.set_option("hot_buckets", hot)
+        ans = v.search(c["X"], k)
+        assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), o_lab, o_dis, ad,
+                            what=f"cfg{seed} bucket_bits={bucket_bits} qb={qb} slices={slices} ea={ea} hot={hot}")
+
+
 @pytest.mark.parametrize("bits", [[8] * 16, [12, 10, 9, 8, 8, 7, 6, 4]], ids=["m16", "nonuniform"])
 def test_seeded_multislice(vaqlib, oracle, bits):
     """Few queries over many rows: rows are split over hundreds of workgroups,

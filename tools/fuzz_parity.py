@@ -63,6 +63,9 @@ while time.time() - t0 < budget:
                   integer=bool(rng.integers(0, 4) == 0), rotate=bool(rng.integers(0, 2)))
     v = vaq_amd.VaqHip()
     v.mBitsAlloc = bits; v.mCentroidsPerSubs = c["cents"]; v.mEigenVectors = c["eig"]; v.mCodebook = c["codes"]
+    if rng.integers(0, 2):  # bucket key width (incl. keys that continue into the second code)
+        v._ensure_index()
+        v.set_option("bucket_bits", int(rng.integers(1, 13)))
     Xp = po.project(c["X"], c["eig"]) if c["eig"] is not None else c["X"]
     o_lab, o_dis = po.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
     ad = np.stack([po.all_dists(po.create_lut(Xp[q], c["cents"], max(bits)), c["codes"]) for q in range(nq)])

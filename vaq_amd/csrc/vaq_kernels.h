@@ -48,6 +48,7 @@ struct ScanParams {
   const int *bucket_start;// [n_buckets + 1] first sorted row of each subspace-0 code
   int n_buckets;          // 1 << (bits[0] - bucket_shift)
   int bucket_shift;       // bucket = first code >> bucket_shift
+  int bucket_t;           // (bucket_shift == 0) bucket = first code << bucket_t | top bucket_t bits of code 1
   int n_hot;              // buckets a workgroup scans best-first before the rest (0 = off, <= 32)
   const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
   const float *lut;       // [nq][lut_floats]
@@ -115,8 +116,8 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 // Stable sort of rows by their subspace-0 code: d_perm[n] (sorted row -> original
 // row) and d_bucket_start[(1<<bits0)+1] (first sorted row of each code that
 // occurs, -1 otherwise; the caller back-fills).  Synchronises the stream.
-hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift,
-                              uint32_t *d_perm, int *d_bucket_start, hipStream_t st);
+hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift, int bits1,
+                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st);
 // Best-first slice order per query batch (n_slices <= 4096, n_buckets <= 4096)
 hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, const int *bstart,
                               int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,
@@ -125,7 +126,7 @@ hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, 
 void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap);
 // bytes of LDS a scan workgroup of `nwaves` wavefronts needs
 size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves,
-                      int n_buckets, int bucket_shift);
+                      int n_buckets, int bucket_shift, int bucket_t);
 // rows one step of the LARGEST workgroup covers: slice_rows and the code
 // buffer's padding must be multiples of it
 int scan_wg_step_rows(int layout, int M);

@@ -257,11 +257,13 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 //   bucket_start[b]  first sorted row whose code 0 is >= b  (b = 0 .. K0)
 // ---------------------------------------------------------------------------
 __global__ void first_code_keys_kernel(const uint16_t *__restrict__ codes, int64_t n, int M,
-                                       unsigned mask, int shift, uint16_t *__restrict__ keys,
-                                       uint32_t *__restrict__ idx) {
+                                       unsigned mask, int shift, unsigned mask1, int shift1, int t,
+                                       uint16_t *__restrict__ keys, uint32_t *__restrict__ idx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  keys[i] = (uint16_t)((codes[i * M] & mask) >> shift);
+  unsigned key = (codes[i * M] & mask) >> shift;
+  if (t > 0) key = (key << t) | ((codes[i * M + 1] & mask1) >> shift1);  // + top t bits of code 1
+  keys[i] = (uint16_t)key;
   idx[i] = (uint32_t)i;
 }
 
@@ -272,9 +274,10 @@ __global__ void bucket_bounds_kernel(const uint16_t *__restrict__ keys, int64_t 
   if (i == 0 || keys[i] != keys[i - 1]) start[keys[i]] = (int)i;
 }
 
-hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift,
-                              uint32_t *d_perm, int *d_bucket_start, hipStream_t st) {
-  const int K0 = 1 << (bits0 - shift);  // buckets: the first code's top bits0 - shift bits
+hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift, int bits1,
+                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st) {
+  const int kbits = bits0 - shift + t;  // key: the first code's top bits0 - shift bits [+ t of code 1]
+  const int K0 = 1 << kbits;
   hipError_t e = hipMemsetAsync(d_bucket_start, 0xff, (size_t)(K0 + 1) * sizeof(int), st);
   if (e != hipSuccess || n == 0) return e;
   uint16_t *keys_in = nullptr, *keys_out = nullptr;
@@ -291,14 +294,15 @@ hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bit
   }
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(first_code_keys_kernel, dim3(blocks), dim3(256), 0, st, d_codes, n, M,
-                     (unsigned)((1 << bits0) - 1), shift, keys_in, idx_in);
+                     (unsigned)((1 << bits0) - 1), shift, (unsigned)((1 << bits1) - 1), bits1 - t, t, keys_in,
+                     idx_in);
   // stable LSD radix sort on the b0 key bits: equal codes keep ascending original rows
   e = rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
-                                (unsigned)(bits0 - shift), st);
+                                (unsigned)kbits, st);
   if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
   if (e == hipSuccess)
     e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
-                                  (unsigned)(bits0 - shift), st);
+                                  (unsigned)kbits, st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(bucket_bounds_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, d_bucket_start);
     e = hipGetLastError();
@@ -575,6 +579,7 @@ constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
 #define VAQ_HOT_SEG 16
 #endif
 constexpr int HOT_SEG_STEPS = VAQ_HOT_SEG;  // wave steps per best-first work unit
+constexpr int GMIN_MAX_BITS = 4;  // at most this many bits of the second code extend the bucket key
 constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
 
 // TI form: begin / end / centre distance / farthest member per visited cluster + unit prefix
@@ -632,7 +637,9 @@ template <int QB, bool SQ> struct ScanCtx {
   // query batch are scanned before the rest (so the thresholds are near-final
   // when the remaining buckets are tested for skipping)
   LT *lb;              // [n_buckets] per-bucket lower bound of the first term (== lut when shift == 0)
-  int bshift;          // bucket = first code >> bshift
+  int bshift;          // bucket = first code >> bshift ...
+  int bt;              // ... or (bshift == 0) first code << bt | top bt bits of the second code
+  unsigned *gmin;      // [QB][1 << bt] float bits: smallest second term of each group of second codes
   int *hot_bucket;     // [HOT_MAX] bucket ids in ascending-key order, -1 = none
   int *hot_pre;        // [HOT_MAX + 1] prefix of segment counts
   unsigned *hot_mask;  // [HOT_MASK_WORDS] bit b set = bucket b is handled by the hot phase
@@ -664,13 +671,23 @@ template <int QB, bool SQ> struct ScanCtx {
         const int s0 = bstart[b] > r0 ? bstart[b] : r0;
         const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
         if (e0 > s0) {
-          // smallest first term any row of the bucket can have, over the batch's queries
+          // smallest first term (bt > 0: first + second term) any row of the bucket can have,
+          // over the batch's queries
           float m = INFINITY;
-          for (int c = b << p.bucket_shift; c < ((b + 1) << p.bucket_shift); c++) {
+          if (bt > 0) {
 #pragma unroll
             for (int q = 0; q < QB; q++) {
-              const float x = p.lut[(size_t)qi[q] * p.lut_floats + c];
+              const float x = p.lut[(size_t)qi[q] * p.lut_floats + (b >> bt)] +
+                              bits_to_float(gmin[(q << bt) + (b & ((1 << bt) - 1))]);
               m = x < m ? x : m;
+            }
+          } else {
+            for (int c = b << p.bucket_shift; c < ((b + 1) << p.bucket_shift); c++) {
+#pragma unroll
+              for (int q = 0; q < QB; q++) {
+                const float x = p.lut[(size_t)qi[q] * p.lut_floats + c];
+                m = x < m ? x : m;
+              }
             }
           }
           key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
@@ -762,12 +779,16 @@ template <int QB, bool SQ> struct ScanCtx {
     off += QB * sb;
     n_hot = p.n_hot;
     bshift = p.bucket_shift;
-    lb = bshift > 0 ? reinterpret_cast<LT *>(smem + off) : lut;
-    if (bshift > 0) off += ((size_t)p.n_buckets * sizeof(LT) + 15) & ~(size_t)15;
+    bt = p.bucket_t;
+    lb = (bshift > 0 || bt > 0) ? reinterpret_cast<LT *>(smem + off) : lut;
+    if (bshift > 0 || bt > 0) off += ((size_t)p.n_buckets * sizeof(LT) + 15) & ~(size_t)15;
     hot_bucket = reinterpret_cast<int *>(smem + off);
     hot_pre = hot_bucket + HOT_MAX;
     hot_mask = reinterpret_cast<unsigned *>(hot_pre + HOT_MAX + 1);
     hot_ticket = hot_mask + HOT_MASK_WORDS;
+    // (borrows the first query's candidate slots: 4 << GMIN_MAX_BITS <= ccap words, consumed by
+    //  pick_hot / stage_lut before the first admission writes there)
+    gmin = reinterpret_cast<unsigned *>(sel[0].d + p.kp);
     off += HOT_BYTES;
     ti_nv = 0;
     ti_rows_before = 0;
@@ -845,6 +866,20 @@ template <int QB, bool SQ> struct ScanCtx {
     __syncthreads();
   }
 
+  // bt > 0: the minimum of the second table over each group of 1 << (bits1 - bt) codes, per
+  // query (entries are >= 0, so their bit patterns order like the values)
+  __device__ __forceinline__ void stage_gmin(const ScanParams &p, int off1, int ncent1, int tid, int nthreads) {
+    if (bt == 0) return;
+    for (int i = tid; i < (QB << bt); i += nthreads) gmin[i] = 0x7f800000u;
+    __syncthreads();
+    const int w = 31 - __builtin_clz((unsigned)ncent1) - bt;  // log2 of the group size
+#pragma unroll
+    for (int q = 0; q < QB; q++)
+      for (int e = tid; e < ncent1; e += nthreads)
+        atomicMin(&gmin[(q << bt) + (e >> w)], float_to_bits(p.lut[(size_t)qi[q] * p.lut_floats + off1 + e]));
+    __syncthreads();
+  }
+
   // copy the batch's LUTs into LDS, interleaved per entry (after pick_hot, which borrows the region)
   __device__ __forceinline__ void stage_lut(const ScanParams &p, int lut_entries, int tid, int nthreads) {
     for (int e = tid; e < lut_entries; e += nthreads) {
@@ -863,6 +898,16 @@ template <int QB, bool SQ> struct ScanCtx {
           for (int q = 0; q < QB; q++)
             if (lv_get<QB>(x, q) < lv_get<QB>(m, q)) lv_set<QB>(m, q, lv_get<QB>(x, q));
         }
+        lb[b] = m;
+      }
+    } else if (bt > 0) {  // first term + the smallest second term of the bucket's group
+      __syncthreads();
+      for (int b = tid; b < p.n_buckets; b += nthreads) {
+        const LT l0 = lut[b >> bt];
+        LT m;
+#pragma unroll
+        for (int q = 0; q < QB; q++)
+          lv_set<QB>(m, q, lv_get<QB>(l0, q) + bits_to_float(gmin[(q << bt) + (b & ((1 << bt) - 1))]));
         lb[b] = m;
       }
     }
@@ -1076,6 +1121,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
 
   ScanCtx<QB, TI> cx;
   cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
+  if (!TI && EA != EA_NONE) cx.stage_gmin(p, 256, 256, tid, nthreads);
   if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
   if (TI) cx.stage_ti(p, 0, HOT_SEG_STEPS * 64 * Item::ROWS, 64 * Item::ROWS, tid, nthreads);
@@ -1181,13 +1227,21 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     int ti_cur = 0, ti_c0 = 0;
     const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
+    // bucket starts are read 64 at a time (lane i: the start of bucket cbase + i) and picked
+    // out with v_readlane: one global read per 64 buckets instead of a dependent one per bucket
+    int cbase = 0, cval = 0;
     if (!TI && w0 < w1) {
-      int lo = 0, hi = p.n_buckets;  // largest b with bstart[b] <= w0
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bstart[mid] <= w0) lo = mid; else hi = mid;
-      }
-      wb = lo;
+      // largest b with bstart[b] <= w0, by two 64-way steps (n_buckets <= 4096)
+      const int K0 = p.n_buckets;
+      const int stride = (K0 + 63) >> 6;
+      int i1 = lane * stride;
+      const bool le1 = i1 < K0 && bstart[i1] <= w0;  // monotone in the lane: a prefix of lanes is true
+      const int blk = __popcll(__ballot(le1)) - 1;   // bstart[0] = 0 <= w0, so blk >= 0
+      int i2 = blk * stride + lane;
+      const bool le2 = lane < stride && i2 < K0 && bstart[i2] <= w0;
+      wb = blk * stride + __popcll(__ballot(le2)) - 1;
+      cbase = wb;
+      cval = bstart[(cbase + lane) < K0 ? cbase + lane : K0];
     }
     for (;;) {
       int b = 0, pos, be;
@@ -1249,7 +1303,15 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
         if (be > bend) be = bend;
       } else {
         if (wpos >= w1) break;
-        be = bstart[wb + 1];
+        {
+          int ci = wb + 1 - cbase;
+          if (ci >= 64) {
+            cbase = wb + 1;
+            cval = bstart[(cbase + lane) < p.n_buckets ? cbase + lane : p.n_buckets];
+            ci = 0;
+          }
+          be = __builtin_amdgcn_readlane(cval, __builtin_amdgcn_readfirstlane(ci));
+        }
         if (be > w1) be = w1;
         if (be <= wpos) { wb++; continue; }
         b = wb;
@@ -1264,13 +1326,19 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
           float l0[QB];
 #pragma unroll
           for (int q = 0; q < QB; q++) l0[q] = 0.0f;
-          if (!TI) {
-            const LT l0v = cx.lb[b];
+          float lbq[QB];  // lower bound of every row sum of the bucket
 #pragma unroll
-            for (int q = 0; q < QB; q++)
+          for (int q = 0; q < QB; q++) lbq[q] = 0.0f;
+          if (!TI) {
+            const LT lbv = cx.lb[b];
+            const LT l0v = cx.bt > 0 ? lut[b >> cx.bt] : lbv;  // the rows' (shared) first term
+#pragma unroll
+            for (int q = 0; q < QB; q++) {
+              lbq[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(lbv, q))));
               l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+            }
           }
-          if (TI || cx.survives(l0)) {  // otherwise no row of the bucket can be admitted: skip its codes
+          if (TI || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
             Item pf[PREFETCH];
@@ -1389,6 +1457,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
 
   ScanCtx<QB, TI> cx;
   cx.setup(smem, p, p.lut_lds_entries, qbatch, tid, nthreads);
+  if (!TI && EA != EA_NONE && p.M > 1) cx.stage_gmin(p, p.sub[1].lut_off, p.sub[1].ncent, tid, nthreads);
   if (!TI && EA != EA_NONE && cx.n_hot > 0)
     cx.pick_hot(smem, p, r0, r1, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
   if (TI) cx.stage_ti(p, 0, HOT_SEG_STEPS * TILE_ROWS, TILE_ROWS, tid, nthreads);
@@ -1533,13 +1602,21 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
     int ti_cur = 0, ti_c0 = 0;
     const float *__restrict__ xcc = p.ti_xcc;
     int wb = 0, wpos = w0, stepno = 0;
+    // bucket starts are read 64 at a time (lane i: the start of bucket cbase + i) and picked
+    // out with v_readlane: one global read per 64 buckets instead of a dependent one per bucket
+    int cbase = 0, cval = 0;
     if (!TI && w0 < w1) {
-      int lo = 0, hi = p.n_buckets;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bstart[mid] <= w0) lo = mid; else hi = mid;
-      }
-      wb = lo;
+      // largest b with bstart[b] <= w0, by two 64-way steps (n_buckets <= 4096)
+      const int K0 = p.n_buckets;
+      const int stride = (K0 + 63) >> 6;
+      int i1 = lane * stride;
+      const bool le1 = i1 < K0 && bstart[i1] <= w0;  // monotone in the lane: a prefix of lanes is true
+      const int blk = __popcll(__ballot(le1)) - 1;   // bstart[0] = 0 <= w0, so blk >= 0
+      int i2 = blk * stride + lane;
+      const bool le2 = lane < stride && i2 < K0 && bstart[i2] <= w0;
+      wb = blk * stride + __popcll(__ballot(le2)) - 1;
+      cbase = wb;
+      cval = bstart[(cbase + lane) < K0 ? cbase + lane : K0];
     }
     for (;;) {
       int b = 0, pos, be;
@@ -1598,7 +1675,15 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
         if (be > bend) be = bend;
       } else {
         if (wpos >= w1) break;
-        be = bstart[wb + 1];
+        {
+          int ci = wb + 1 - cbase;
+          if (ci >= 64) {
+            cbase = wb + 1;
+            cval = bstart[(cbase + lane) < p.n_buckets ? cbase + lane : p.n_buckets];
+            ci = 0;
+          }
+          be = __builtin_amdgcn_readlane(cval, __builtin_amdgcn_readfirstlane(ci));
+        }
         if (be > w1) be = w1;
         if (be <= wpos) { wb++; continue; }
         b = wb;
@@ -1612,13 +1697,20 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
           float l0[QB];
 #pragma unroll
           for (int q = 0; q < QB; q++) l0[q] = 0.0f;
-          if (!TI) {
-            const LT l0v = cx.lb[b];  // first term (or its lower bound); subspace 0's table starts the packed LUT
+          float lbq[QB];
 #pragma unroll
-            for (int q = 0; q < QB; q++)
+          for (int q = 0; q < QB; q++) lbq[q] = 0.0f;
+          if (!TI) {
+            const LT lbv = cx.lb[b];  // lower bound of the bucket's row sums
+            // the rows' shared first term (subspace 0's table starts the packed LUT), or its bound
+            const LT l0v = cx.bt > 0 ? lut[b >> cx.bt] : lbv;
+#pragma unroll
+            for (int q = 0; q < QB; q++) {
+              lbq[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(lbv, q))));
               l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
+            }
           }
-          if (TI || cx.survives(l0)) {
+          if (TI || cx.survives(lbq)) {
             const int base0 = pos & ~(TILE_ROWS - 1);
             const int nst = (be - base0 + TILE_ROWS - 1) / TILE_ROWS;
             Item pf[PREFETCH];
@@ -1779,6 +1871,13 @@ template <int W, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bits_kernel(ScanParams p) {
   scan_bits_body<W, QB, EA, false, false>(p);
 }
+// one query per pass: kept within 64 VGPRs so that 8 waves fit a SIMD (the generic build of
+// the early-abandon form needs 65 and loses a wave; measured on C3)
+template <int W, int EA>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS __attribute__((amdgpu_waves_per_eu(8, 8)))
+void scan_bits_q1_kernel(ScanParams p) {
+  scan_bits_body<W, 1, EA, false, false>(p);
+}
 template <int W, int QB>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bits_inplace_kernel(ScanParams p) {
   scan_bits_body<W, QB, EA_INPLACE, false, false>(p);
@@ -1815,13 +1914,13 @@ void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qc
 
 // lut_floats: LUT entries staged in LDS (all of them, or the resident prefix of the bit-packed path)
 size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, int nwaves,
-                      int n_buckets, int bucket_shift) {
+                      int n_buckets, int bucket_shift, int bucket_t) {
   int kp, ccap, qcap;
   scan_geometry(layout, M, k, ea, &kp, &ccap, &qcap);
   size_t lut = (size_t)(layout == LAYOUT_BYTES ? M * 256 : lut_floats) * 4 * qb;
   lut = (lut + 15) & ~(size_t)15;
   const size_t sb = ((size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8 + 15) & ~(size_t)15;
-  const size_t lbb = bucket_shift > 0 ? (((size_t)n_buckets * 4 * qb + 15) & ~(size_t)15) : 0;
+  const size_t lbb = (bucket_shift > 0 || bucket_t > 0) ? (((size_t)n_buckets * 4 * qb + 15) & ~(size_t)15) : 0;
   return lut + (size_t)qb * sb + lbb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
 }
 
@@ -1873,9 +1972,11 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
   size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
-                              p.bucket_shift);
+                              p.bucket_shift, p.bucket_t);
+  if (p.bucket_t < 0 || p.bucket_t > GMIN_MAX_BITS || (p.bucket_t > 0 && p.bucket_shift != 0))
+    return hipErrorInvalidValue;
   if (p.ti) {
-    if (p.qb != 1 || p.ea != EA_QUEUE || p.bucket_shift != 0 || p.n_hot != 0 || !p.sqrt_out)
+    if (p.qb != 1 || p.ea != EA_QUEUE || p.bucket_shift != 0 || p.bucket_t != 0 || p.n_hot != 0 || !p.sqrt_out)
       return hipErrorInvalidValue;
     if (p.ti_cap < 1 || p.ti_cap > p.n_buckets) return hipErrorInvalidValue;
     lds += ti_lds_bytes(p.ti_cap);
@@ -1921,15 +2022,24 @@ hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
     default: return hipErrorInvalidValue;
     }
   }
+#define VAQ_DISPATCH_BITS(A)                                                              \
+  if (p.qb == 1 && p.ea == EA_NONE) return launch_scan_kernel(scan_bits_q1_kernel<A, EA_NONE>, p, lds, grid, st);   \
+  if (p.qb == 1 && p.ea == EA_QUEUE) return launch_scan_kernel(scan_bits_q1_kernel<A, EA_QUEUE>, p, lds, grid, st); \
+  switch (p.qb) {                                                                         \
+  case 1: return launch_scan_kernel(scan_bits_inplace_kernel<A, 1>, p, lds, grid, st);    \
+  case 2: VAQ_DISPATCH_EA(scan_bits, A, 2)                                                \
+  case 4: VAQ_DISPATCH_EA(scan_bits, A, 4)                                                \
+  default: return hipErrorInvalidValue;                                                   \
+  }
   switch (p.W) {
-  case 1: VAQ_DISPATCH_QB(scan_bits, 1)
-  case 2: VAQ_DISPATCH_QB(scan_bits, 2)
-  case 3: VAQ_DISPATCH_QB(scan_bits, 3)
-  case 4: VAQ_DISPATCH_QB(scan_bits, 4)
-  case 5: VAQ_DISPATCH_QB(scan_bits, 5)
-  case 6: VAQ_DISPATCH_QB(scan_bits, 6)
-  case 7: VAQ_DISPATCH_QB(scan_bits, 7)
-  case 8: VAQ_DISPATCH_QB(scan_bits, 8)
+  case 1: VAQ_DISPATCH_BITS(1)
+  case 2: VAQ_DISPATCH_BITS(2)
+  case 3: VAQ_DISPATCH_BITS(3)
+  case 4: VAQ_DISPATCH_BITS(4)
+  case 5: VAQ_DISPATCH_BITS(5)
+  case 6: VAQ_DISPATCH_BITS(6)
+  case 7: VAQ_DISPATCH_BITS(7)
+  case 8: VAQ_DISPATCH_BITS(8)
   default: return hipErrorInvalidValue;
   }
 }

@@ -62,6 +62,7 @@ struct DevBuf {
 constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
+constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
 constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short to need seeding
 constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
@@ -78,7 +79,7 @@ struct vaqhip_index {
   DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
   bool has_eig = false;
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
-  int bucket_shift = 0, n_buckets = 1;  // bucketed row order (set with the codes)
+  int bucket_shift = 0, bucket_t = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
   // triangle-inequality form (VAQ::clusterTI): rows grouped by cluster instead of by first
   // code; d_bstart then holds the cluster starts, n_buckets = ti_T, bucket_shift = 0
@@ -90,7 +91,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -161,10 +162,13 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       for (int nw : {4, 8, 16}) {
         if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
         const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, nw, ix->n_buckets,
-                                               ix->bucket_shift);
+                                               ix->bucket_shift, ix->bucket_t);
         if (lds > LDS_LIMIT) continue;
         const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
-        if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
+        // 16 waves share one admission lock and one ticket: measured much slower than 8 at equal
+        // residency (C3: 5.8 vs 3.1 ms), so they must buy > 1.5x the waves to be chosen
+        const int score = nw == 16 ? (wgs * nw * 2) / 3 : wgs * nw;
+        if (score > best_waves) { best_waves = score; best_nw = nw; }
       }
       if (best_nw) break;
     }
@@ -183,7 +187,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   pl->nwaves = best_nw;
   vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
   pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, best_nw, ix->n_buckets,
-                                ix->bucket_shift);
+                                ix->bucket_shift, ix->bucket_t);
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const int64_t N = ix->N;
   const int nqb = (nq + qb - 1) / qb;
@@ -212,7 +216,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   // best-first slice order (slice_order_kernel): an alternative to the pre-pass, off by default --
   // measured slower (250M rows, 2 queries: 1.21 vs 0.70 ms; 32 queries: 8.7 vs 5.6 ms): the first
   // wave of workgroups all starts cold, and batches no longer share a slice's rows through L2
-  pl->ordered = ea && ix->opt_order && s > 1 && s <= 4096 && ix->n_buckets <= 4096;
+  pl->ordered = ea && ix->opt_order && s > 1 && s <= 4096 && ix->n_buckets <= 4096 && ix->bucket_t == 0;
   if (ea && ix->opt_seed && !pl->ordered && s >= SEED_MIN_SLICES && N >= SEED_MIN_ROWS) {
     const int64_t sample = std::max<int64_t>(N / ix->opt_seed_frac, (int64_t)16 * k);
     // small workgroups (4 waves) and many slices: the pre-pass runs with cold
@@ -246,7 +250,7 @@ int make_ti_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
     best_waves = 0;
     for (int nw : {4, 8, 16}) {
       if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
-      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, nw, ix->ti_T, 0) + ti_bytes;
+      const size_t lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, nw, ix->ti_T, 0, 0) + ti_bytes;
       if (lds > LDS_LIMIT) continue;
       const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
       if (wgs * nw > best_waves) { best_waves = wgs * nw; best_nw = nw; }
@@ -263,7 +267,7 @@ int make_ti_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   pl->ea = ea;
   pl->nwaves = best_nw;
   vaq::scan_geometry(ix->layout, ix->M, k, ea, &pl->kp, &pl->ccap, &pl->qcap);
-  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, best_nw, ix->ti_T, 0) + ti_bytes;
+  pl->lds = vaq::scan_lds_bytes(ix->layout, ix->M, entries, qb, k, ea, best_nw, ix->ti_T, 0, 0) + ti_bytes;
   int64_t s;
   if (ix->opt_slices > 0) s = ix->opt_slices;
   else {
@@ -369,6 +373,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bucket_start = ix->d_bstart.as<int>();
     sp.n_buckets = ix->n_buckets;
     sp.bucket_shift = ix->bucket_shift;
+    sp.bucket_t = ix->bucket_t;
     sp.n_hot = 0;
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
@@ -477,7 +482,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       sp.final_dist = d_dist + (size_t)q0 * k;
     }
     // best-first buckets pay when a workgroup's slice spans many buckets
+    // (its ranking scratch, one word per bucket, borrows the LDS region of the lookup tables)
     sp.n_hot = (ix->opt_hot && sp.n_buckets >= 16 && sp.n_buckets <= 4096 &&
+                (int64_t)sp.n_buckets <= (int64_t)(ix->layout == vaq::LAYOUT_BYTES ? ix->M * 256 : pl.lut_lds_entries) * pl.qb &&
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
@@ -640,18 +647,25 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
   HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
   const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
-  int shift = 0, K0 = 1;
+  int shift = 0, bt = 0, K0 = 1;
   if (ix->ti_T > 0) {
     K0 = ix->ti_T;
   } else {
-    // bucket = top bits of the first code, coarse enough that buckets average >= ~2048 rows
-    // (at most 4096 buckets; at most 1024 when coarser than the code itself)
-    int kb = ix->bits[0];
-    while (kb > 4 && ((int64_t)1 << kb) * 2048 > std::max<int64_t>(N, 1)) kb--;
-    if (kb > 12) kb = 12;
-    if (kb < ix->bits[0] && kb > 10) kb = 10;
+    // bucket key = the top bits of the first code, continued -- when the whole first code is
+    // used up -- by up to 4 top bits of the second: as many key bits as keep ~1000 rows per
+    // bucket on average (at most 4096 buckets; at most 1024 unless the database is large)
+    int want = 4;
+    while (want < 12 && ((int64_t)2 << want) * BUCKET_MIN_ROWS <= std::max<int64_t>(N, 1)) want++;
+    if (want > 10 && N < ((int64_t)1 << 26)) want = 10;
+    if (ix->opt_bucket_bits > 0) want = ix->opt_bucket_bits;
+    const int kb = std::min(want, ix->bits[0]);
     shift = ix->bits[0] - kb;
-    K0 = 1 << kb;
+    // (continuing into the second code pays on large databases -- 250M rows, 32 queries: 4.0 vs
+    //  5.3 ms -- and costs on small ones, where the per-bucket bookkeeping outweighs it: 1M rows,
+    //  10 bits: 2.0 vs 1.45 ms; an explicit "bucket_bits" option is obeyed as given)
+    if (shift == 0 && ix->M > 1 && (N >= ((int64_t)1 << 24) || ix->opt_bucket_bits > 0))
+      bt = std::min(std::min(want - kb, 4), ix->bits[1]);
+    K0 = 1 << (kb + bt);
   }
   HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
   HIP_TRY(ix->d_perm.ensure(std::max<size_t>((size_t)N, 1) * sizeof(uint32_t)));
@@ -665,8 +679,8 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
                                  ix->d_ti_clusters.as<float>(), ix->ti_T, ix->d_perm.as<uint32_t>(),
                                  ix->d_bstart.as<int>(), ix->d_ti_xcc.as<float>(), st));
     else
-      HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->d_perm.as<uint32_t>(),
-                                      ix->d_bstart.as<int>(), st));
+      HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->M > 1 ? ix->bits[1] : 0, bt,
+                                      ix->d_perm.as<uint32_t>(), ix->d_bstart.as<int>(), st));
     HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
     bstart[K0] = (int)N;
     for (int b = K0 - 1; b >= 0; b--)
@@ -678,6 +692,7 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
   ix->N = N;
   ix->bucket_shift = shift;
+  ix->bucket_t = bt;
   ix->n_buckets = K0;
   return VAQHIP_OK;
 }
@@ -1071,6 +1086,9 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "hot_buckets") {
     if (value < 0 || value > 32) return fail(VAQHIP_EINVAL, "hot_buckets must be 0..32");
     ix->opt_hot = (int)value;
+  } else if (k == "bucket_bits") {
+    if (value < 0 || value > 12) return fail(VAQHIP_EINVAL, "bucket_bits must be 0..12");
+    ix->opt_bucket_bits = (int)value;  // takes effect when the codes are (re)set
   } else if (k == "seed_thresholds") {
     ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
