@@ -60,6 +60,7 @@ struct ScanParams {
   int kp;                 // power of two >= k: slots of a workgroup's best list (per query)
   int ccap;               // slots of its candidate region
   int qcap;               // slots of a wave's survivor queue (early abandon)
+  int q_cw_words;         // code dwords per queue entry (set by launch_scan)
   int nwaves;             // wavefronts per workgroup
   int ea;                 // EarlyAbandon
   unsigned *g_thr;        // [nq] shared threshold distances (float bits), preset to FLT_MAX

@@ -574,13 +574,16 @@ constexpr int THR_GLOBAL_EVERY = 64;
 #endif
 constexpr int HOT_MAX = VAQ_HOT_MAX;   // buckets scanned best-first
 constexpr int HOT_MAX_BUCKETS = 4096;  // best-first needs 1 << bits[0] <= this (rank scratch, mask)
-constexpr int HOT_MASK_WORDS = HOT_MAX_BUCKETS / 32;
 #ifndef VAQ_HOT_SEG
 #define VAQ_HOT_SEG 16
 #endif
 constexpr int HOT_SEG_STEPS = VAQ_HOT_SEG;  // wave steps per best-first work unit
 constexpr int GMIN_MAX_BITS = 4;  // at most this many bits of the second code extend the bucket key
-constexpr int HOT_BYTES = ((HOT_MAX + HOT_MAX + 1 + HOT_MASK_WORDS + 1) * 4 + 15) & ~15;
+// hot bucket ids, unit prefix, their row ranges, one mask bit per bucket, the ticket
+__host__ __device__ inline int hot_mask_words(int n_buckets) { return (n_buckets + 31) / 32; }
+__host__ __device__ inline size_t hot_bytes(int n_buckets) {
+  return ((size_t)(HOT_MAX * 4 + 1 + hot_mask_words(n_buckets) + 1) * 4 + 15) & ~(size_t)15;
+}
 
 // TI form: begin / end / centre distance / farthest member per visited cluster + unit prefix
 __host__ __device__ inline size_t ti_lds_bytes(int n_clusters) {
@@ -627,6 +630,7 @@ template <int QB, bool SQ> struct ScanCtx {
   int qi[QB];
   int *q_id;         // survivor queue (wave-private): row id
   float *q_p;        // [QB][qcap]: sum of the row's first group of four subspaces
+  uint32_t *q_cw;    // [q_cw_words][qcap]: the row's code dwords 1.. (byte codes, M <= 16)
   int qcap, qcnt;
   int lane, wave, nwaves;
   int k, kp, ccap;
@@ -642,7 +646,8 @@ template <int QB, bool SQ> struct ScanCtx {
   unsigned *gmin;      // [QB][1 << bt] float bits: smallest second term of each group of second codes
   int *hot_bucket;     // [HOT_MAX] bucket ids in ascending-key order, -1 = none
   int *hot_pre;        // [HOT_MAX + 1] prefix of segment counts
-  unsigned *hot_mask;  // [HOT_MASK_WORDS] bit b set = bucket b is handled by the hot phase
+  int *hot_bs, *hot_be;  // [HOT_MAX] the bucket's rows inside the slice (no global read per segment)
+  unsigned *hot_mask;  // [hot_mask_words(n_buckets)] bit b set = bucket b is handled by the hot phase
   unsigned *hot_ticket;
   int n_hot;
   // triangle-inequality form: the query's visiting list (QB == 1)
@@ -711,22 +716,29 @@ template <int QB, bool SQ> struct ScanCtx {
       const unsigned k = (i < K0p) ? tmp[i] : 0xffffffffu;
       hot_bucket[i] = (i < p.n_hot && k != 0xffffffffu) ? (int)(k & idx_mask) : -1;
     }
-    for (int w = tid; w < HOT_MASK_WORDS; w += nthreads) hot_mask[w] = 0u;
+    for (int w = tid; w < hot_mask_words(K0); w += nthreads) hot_mask[w] = 0u;
     __syncthreads();
-    if (tid == 0) {
-      int acc = 0;
-      for (int i = 0; i < HOT_MAX; i++) {
-        hot_pre[i] = acc;
-        const int b = hot_bucket[i];
-        if (b >= 0) {
-          const int s0 = bstart[b] > r0 ? bstart[b] : r0;
-          const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
-          acc += (e0 - (s0 & ~(wstep - 1)) + seg_rows - 1) / seg_rows;
-          hot_mask[b >> 5] |= 1u << (b & 31);
-        }
+    if (tid < 64) {  // wave 0: one hot bucket per lane, segment counts prefix-summed across lanes
+      static_assert(HOT_MAX <= 64, "one lane per hot bucket");
+      const int b = tid < HOT_MAX ? hot_bucket[tid] : -1;
+      int segs = 0;
+      if (b >= 0) {
+        const int s0 = bstart[b] > r0 ? bstart[b] : r0;
+        const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        segs = (e0 - (s0 & ~(wstep - 1)) + seg_rows - 1) / seg_rows;
+        atomicOr(&hot_mask[b >> 5], 1u << (b & 31));
+        hot_bs[tid] = s0;
+        hot_be[tid] = e0;
       }
-      hot_pre[HOT_MAX] = acc;
-      *hot_ticket = 0u;
+      int inc = segs;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (tid >= o) inc += v;
+      }
+      if (tid < HOT_MAX) hot_pre[tid] = inc - segs;
+      if (tid == HOT_MAX - 1) hot_pre[HOT_MAX] = inc;
+      if (tid == 0) *hot_ticket = 0u;
     }
     __syncthreads();
   }
@@ -784,12 +796,14 @@ template <int QB, bool SQ> struct ScanCtx {
     if (bshift > 0 || bt > 0) off += ((size_t)p.n_buckets * sizeof(LT) + 15) & ~(size_t)15;
     hot_bucket = reinterpret_cast<int *>(smem + off);
     hot_pre = hot_bucket + HOT_MAX;
-    hot_mask = reinterpret_cast<unsigned *>(hot_pre + HOT_MAX + 1);
-    hot_ticket = hot_mask + HOT_MASK_WORDS;
+    hot_bs = hot_pre + HOT_MAX + 1;
+    hot_be = hot_bs + HOT_MAX;
+    hot_mask = reinterpret_cast<unsigned *>(hot_be + HOT_MAX);
+    hot_ticket = hot_mask + hot_mask_words(p.n_buckets);
     // (borrows the first query's candidate slots: 4 << GMIN_MAX_BITS <= ccap words, consumed by
     //  pick_hot / stage_lut before the first admission writes there)
     gmin = reinterpret_cast<unsigned *>(sel[0].d + p.kp);
-    off += HOT_BYTES;
+    off += hot_bytes(p.n_buckets);
     ti_nv = 0;
     ti_rows_before = 0;
     if (p.ti) {
@@ -800,10 +814,11 @@ template <int QB, bool SQ> struct ScanCtx {
       ti_pre = reinterpret_cast<int *>(ti_x0 + p.ti_cap);
       off += ti_lds_bytes(p.ti_cap);
     }
-    const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB);
+    const size_t q_bytes = (size_t)p.qcap * 4 * (1 + QB + p.q_cw_words);
     unsigned char *qb = smem + off + (size_t)wave * q_bytes;
     q_id = reinterpret_cast<int *>(qb);
     q_p = reinterpret_cast<float *>(qb + (size_t)p.qcap * 4);
+    q_cw = reinterpret_cast<uint32_t *>(q_p + (size_t)QB * p.qcap);
   }
 
   // TI form (VAQ::searchTriangleInequality, VAQ.cpp:1548-1560): the clusters this query
@@ -1003,8 +1018,9 @@ template <int QB, bool SQ> struct ScanCtx {
     }
   }
 
-  // compact the lanes with `alive` set into the survivor queue
-  __device__ __forceinline__ void push(bool alive, int rid, const float (&acc)[QB]) {
+  // compact the lanes with `alive` set into the survivor queue (NCW code dwords ride along)
+  template <int NCW>
+  __device__ __forceinline__ void push(bool alive, int rid, const float (&acc)[QB], const uint32_t *cw) {
     const unsigned long long m = __ballot(alive);
     if (m != 0ull) {
       const int pos = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
@@ -1013,6 +1029,8 @@ template <int QB, bool SQ> struct ScanCtx {
         q_id[pos] = rid;
 #pragma unroll
         for (int q = 0; q < QB; q++) q_p[q * qcap + pos] = acc[q];
+#pragma unroll
+        for (int i = 0; i < NCW; i++) q_cw[i * qcap + pos] = cw[i];
       }
       qcnt += __popcll(m);
     }
@@ -1101,6 +1119,8 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
   constexpr int WPR = Item::WPR;
+  // survivors queue the rest of their row (up to 3 dwords) so that phase B reads LDS, not L2
+  constexpr int QCW = (EA == EA_QUEUE && M <= 16) ? WPR - 1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int nqb = (p.nq + QB - 1) / QB;
@@ -1177,11 +1197,8 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     uint32_t cw[WPR];
     cw[0] = 0u;
 #pragma unroll
-#ifdef VAQ_EXPERIMENT_NO_REREAD   // timing experiment only: results are wrong
-    for (int i = 1; i < WPR; i++) cw[i] = (unsigned)rid * 2654435761u;
-#else
-    for (int i = 1; i < WPR; i++) cw[i] = codes[(int64_t)rid * WPR + i];
-#endif
+    for (int i = 1; i < WPR; i++)
+      cw[i] = QCW > 0 ? cx.q_cw[(i - 1) * cx.qcap + slot] : codes[(int64_t)rid * WPR + i];
     finish(cw, acc, rid, ok);
   };
 
@@ -1293,8 +1310,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
         int i = 0;
         while (cx.hot_pre[i + 1] <= t) i++;
         b = cx.hot_bucket[i];
-        const int bs = bstart[b] > r0 ? bstart[b] : r0;
-        const int bend = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        const int bs = cx.hot_bs[i], bend = cx.hot_be[i];
         const int al = bs & ~(WSTEP - 1);
         const int j = t - cx.hot_pre[i];
         pos = al + j * SEG_ROWS;
@@ -1398,7 +1414,11 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                   live = cx.survives(part[r]);
                 }
                 if (EA == EA_QUEUE) {
-                  cx.push(live, row0 + r, part[r]);
+                  uint32_t rest[WPR];
+#pragma unroll
+                  for (int i = 1; i < WPR; i++) rest[i - 1] = cur.word(r, i);
+                  cx.template push<QCW>(live, row0 + r, part[r], rest);
+                  while (cx.qcnt >= 64) drain(64);  // (per row: the queue never holds more than 127)
                 } else {
                   // EA_INPLACE: the live lanes finish their rows where they stand
                   uint32_t cw[WPR];
@@ -1407,8 +1427,6 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                   finish(cw, part[r], row0 + r, live);
                 }
               }
-              if (EA == EA_QUEUE)
-                while (cx.qcnt >= 64) drain(64);
             }
           }
         }
@@ -1665,8 +1683,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
         int i = 0;
         while (cx.hot_pre[i + 1] <= t) i++;
         b = cx.hot_bucket[i];
-        const int bs = bstart[b] > r0 ? bstart[b] : r0;
-        const int bend = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+        const int bs = cx.hot_bs[i], bend = cx.hot_be[i];
         const int al = bs & ~(WSTEP - 1);
         const int j = t - cx.hot_pre[i];
         pos = al + j * SEG_ROWS;
@@ -1763,7 +1780,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
                 live = cx.survives(seq ? acc : (M > 3 ? acc : dism));
               }
               if (EA == EA_QUEUE) {
-                cx.push(live, row, acc);
+                cx.template push<0>(live, row, acc, nullptr);
                 while (cx.qcnt >= 64) drain(64);
               } else {
                 live = tail_inplace(cur, 4, acc, dism, live, true);
@@ -1904,12 +1921,18 @@ static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && 
 // rows the code buffer and every slice are padded to: one step of the largest workgroup
 int scan_wg_step_rows(int layout, int M) { return SCAN_MAX_THREADS * rows_per_item(layout, M); }
 
+// code dwords a survivor-queue entry carries besides the row id and the partial sums: the
+// rest of the row for byte codes of up to 16 subspaces (phase B then needs no re-read)
+static int queue_code_words(int layout, int M, int ea) {
+  return (layout == LAYOUT_BYTES && M <= 16 && ea == EA_QUEUE) ? M / 4 - 1 : 0;
+}
+
 void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap) {
   int p2 = 1;
   while (p2 < k) p2 <<= 1;
   *kp = p2;
   *ccap = 128;  // a wave appends at most 64 rows per lock hold
-  *qcap = ea == EA_QUEUE ? 64 + 64 * rows_per_item(layout, M) : 0;
+  *qcap = ea == EA_QUEUE ? 128 : 0;  // at most 63 left over + 64 pushed before the next drain
 }
 
 // lut_floats: LUT entries staged in LDS (all of them, or the resident prefix of the bit-packed path)
@@ -1921,7 +1944,8 @@ size_t scan_lds_bytes(int layout, int M, int lut_floats, int qb, int k, int ea, 
   lut = (lut + 15) & ~(size_t)15;
   const size_t sb = ((size_t)SEL_HDR_WORDS * 4 + (size_t)(kp + ccap) * 8 + 15) & ~(size_t)15;
   const size_t lbb = (bucket_shift > 0 || bucket_t > 0) ? (((size_t)n_buckets * 4 * qb + 15) & ~(size_t)15) : 0;
-  return lut + (size_t)qb * sb + lbb + HOT_BYTES + (size_t)nwaves * qcap * 4 * (1 + qb);
+  return lut + (size_t)qb * sb + lbb + hot_bytes(n_buckets) +
+         (size_t)nwaves * qcap * 4 * (1 + qb + queue_code_words(layout, M, ea));
 }
 
 size_t scan_ti_lds_bytes(int n_clusters) { return ti_lds_bytes(n_clusters); }
@@ -1965,7 +1989,9 @@ static hipError_t launch_scan_kernel(K kernel, const ScanParams &p, size_t lds, 
   default: return hipErrorInvalidValue; /* the host plans Qb <= 2 when tables spill */    \
   }
 
-hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st) {
+hipError_t launch_scan(const ScanParams &p_in, int *grid_out, hipStream_t st) {
+  ScanParams p = p_in;
+  p.q_cw_words = queue_code_words(p.layout, p.M, p.ea);
   const int nqb = (p.nq + p.qb - 1) / p.qb;
   const int total = nqb * p.n_slices;
   const int grid = ((total + 7) / 8) * 8;
