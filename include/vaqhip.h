@@ -105,6 +105,15 @@ int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor,
 int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
                                       int64_t N, int64_t id_base, void *stream);
 
+/* Append n_new rows (same layout) behind the rows already in the index; their labels
+ * continue at id_base + N.  Stands for growing `mCodebook` and calling the setter again
+ * (SURVEY.md section 8b lists the entry point as `add_codes`): the rows are re-ordered as a
+ * whole (bucketed or TI order), so an append costs a rebuild of the packed copy -- O(N) on
+ * the GPU, with a temporary of 2*M bytes per row.  Synchronises. */
+int vaqhip_index_add_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor, int64_t n_new);
+int vaqhip_index_add_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
+                                      int64_t n_new, void *stream);
+
 /* VAQ::clusterTI (VAQ.hpp:106, VAQ.cpp:878-999) from the point where mTIClusters
  * exists: `clusters` is mTIClusters, T x (seg_num * D/M) row-major, i.e. T
  * centres over the first seg_num subspaces (mTIClusterNum, mTISegmentNum); how

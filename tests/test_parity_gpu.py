@@ -461,3 +461,26 @@ def test_lock_contention_stress(vaqlib, oracle):
         v2.set_option("slices", [0, 3, 11, 1][rep])
         a = v2.search(c2["X"], k)
         assert_topk_matches(a.labels.reshape(8, k), a.distances.reshape(8, k), o_lab, o_dis, ad, what=f"ties rep {rep}")
+
+
+def test_add_codes_appends_rows(vaqlib, oracle):
+    """vaqhip_index_add_codes_u16: rows appended in three pieces (with an empty start and a TI
+    regroup in between) give the same answers as one index over all of them."""
+    from vaq_amd.index import NNMethod
+    for bits, D in ([8] * 8, 64), ([12, 10, 9, 8, 8, 7, 6, 4], 64):
+        c = make_case(801, D, bits, 30000, 8, dup_frac=0.02)
+        full = c["codes"]
+        v = make_index(dict(c, codes=full[:0]))
+        Xp = oracle.project(c["X"], c["eig"])
+        k = 50
+        a = v.search(c["X"], k)
+        assert np.all(a.labels == -1)
+        v.add_codes(full[:7000])
+        v.add_codes(full[7000:7001])
+        v.add_codes(full[7001:])
+        assert v.info()["N"] == 30000
+        o_lab, o_dis = oracle.search(Xp, c["cents"], full, k, max_bits=max(bits), projected=True)
+        ad = oracle_all_dists(oracle, dict(c, codes=full), Xp)
+        a = v.search(c["X"], k)
+        assert_topk_matches(a.labels.reshape(8, k), a.distances.reshape(8, k), o_lab, o_dis, ad, what="appended")
+        v.close()

@@ -14,7 +14,8 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libvaqhip.so")
 # every symbol include/vaqhip.h declares
 SYMBOLS = [
     "vaqhip_index_create", "vaqhip_index_create_ex", "vaqhip_index_destroy", "vaqhip_index_set_codes_u16",
-    "vaqhip_index_set_codes_u16_device", "vaqhip_index_set_ti_clusters", "vaqhip_index_set_method",
+    "vaqhip_index_set_codes_u16_device", "vaqhip_index_add_codes_u16", "vaqhip_index_add_codes_u16_device",
+    "vaqhip_index_set_ti_clusters", "vaqhip_index_set_method",
     "vaqhip_search", "vaqhip_search_projected",
     "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
     "vaqhip_merge_topk_strided_device",
@@ -87,6 +88,8 @@ def load():
     L.vaqhip_index_destroy.restype = None
     L.vaqhip_index_set_codes_u16.argtypes = [vp, vp, i64, i64]
     L.vaqhip_index_set_codes_u16_device.argtypes = [vp, vp, i64, i64, vp]
+    L.vaqhip_index_add_codes_u16.argtypes = [vp, vp, i64]
+    L.vaqhip_index_add_codes_u16_device.argtypes = [vp, vp, i64, vp]
     L.vaqhip_index_set_ti_clusters.argtypes = [vp, vp, i32, i32]
     L.vaqhip_index_set_method.argtypes = [vp, C.c_uint, C.c_float]
     L.vaqhip_search.argtypes = [vp, vp, i32, i32, vp, vp]

@@ -276,6 +276,18 @@ class VaqHip:
                                                               self.id_base))
         self._codes_sig = sig
 
+    def add_codes(self, codes: np.ndarray) -> None:
+        """Append rows to the index on the device (vaqhip_index_add_codes_u16); the host
+        mCodebook, if still attached, grows with them so the two stay the same matrix."""
+        self._ensure_codes()
+        cb = np.ascontiguousarray(codes, dtype=np.uint16)
+        if cb.ndim != 2 or cb.shape[1] != len(self.mBitsAlloc):
+            raise _lib.VaqHipError(-1, f"codes {cb.shape} is not n x {len(self.mBitsAlloc)}")
+        _lib.check(_lib.load().vaqhip_index_add_codes_u16(self._h, _ptr(cb), cb.shape[0]))
+        if self.mCodebook is not None and not hasattr(self.mCodebook, "data_ptr"):
+            self.mCodebook = np.concatenate([np.asarray(self.mCodebook, dtype=np.uint16), cb])
+            self._codes_sig = (id(self.mCodebook), self.id_base)
+
     # ------------------------------------------------------------- search --
     def search(self, XTest: np.ndarray, k: int, verbose: bool = False,
                projected: bool = False) -> LabelDistVec:
