@@ -565,6 +565,9 @@ constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 #ifndef VAQ_PREFETCH
 #define VAQ_PREFETCH 2
 #endif
+#ifndef VAQ_CCAP
+#define VAQ_CCAP 128
+#endif
 constexpr int PREFETCH = VAQ_PREFETCH;  // items loaded ahead of the one being processed
 constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
 constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
@@ -1931,7 +1934,7 @@ void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qc
   int p2 = 1;
   while (p2 < k) p2 <<= 1;
   *kp = p2;
-  *ccap = 128;  // a wave appends at most 64 rows per lock hold
+  *ccap = VAQ_CCAP;  // a wave appends at most 64 rows per lock hold
   *qcap = ea == EA_QUEUE ? 128 : 0;  // at most 63 left over + 64 pushed before the next drain
 }
 
