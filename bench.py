@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
                                              "seg subspaces (default all), method EA_TI (not the headline metric)")
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
+    ap.add_argument("--no-skip", action="store_true", help="visit every bucket (streaming-rate measurement)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="bits of the first code that key the row buckets (0 = auto)")
     ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
     ap.add_argument("--no-recall", action="store_true")
@@ -218,6 +219,8 @@ def main():
         v.set_option("seed_fraction", args.seed_frac)
     if args.hot >= 0:
         v.set_option("hot_buckets", args.hot)
+    if args.no_skip:
+        v.set_option("bucket_skip", 0)
     info = v.info()
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the

@@ -247,6 +247,11 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       0 never (VAQ::searchHeap as written), 1 survivors are
  *                       compacted through an LDS queue, 2 survivors finish in
  *                       place, 3 (default) 1 or 2 chosen per search            */
+/*   "bucket_bits"       0 (default) = auto, else 1..12: width of the key the rows are bucketed by
+ *                       (top bits of the first code, continued into the second); takes
+ *                       effect when the codes are (re)set
+ *   "bucket_skip"       1 (default); 0 visits every bucket -- for measuring the streaming
+ *                       rate of the scan, results are the same                             */
 int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
 
 typedef struct {

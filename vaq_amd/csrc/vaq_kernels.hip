@@ -1357,7 +1357,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
               l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
             }
           }
-          if (TI || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
+          if (TI || p.no_skip || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
             Item pf[PREFETCH];
@@ -1730,7 +1730,7 @@ __device__ __forceinline__ void scan_bits_body(const ScanParams &p) {
               l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
             }
           }
-          if (TI || cx.survives(lbq)) {
+          if (TI || p.no_skip || cx.survives(lbq)) {
             const int base0 = pos & ~(TILE_ROWS - 1);
             const int nst = (be - base0 + TILE_ROWS - 1) / TILE_ROWS;
             Item pf[PREFETCH];

@@ -91,7 +91,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -375,6 +375,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bucket_shift = ix->bucket_shift;
     sp.bucket_t = ix->bucket_t;
     sp.n_hot = 0;
+    sp.no_skip = ix->opt_no_skip;
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
     sp.lds_subs = pl.lds_subs;
@@ -1122,6 +1123,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "hot_buckets") {
     if (value < 0 || value > 32) return fail(VAQHIP_EINVAL, "hot_buckets must be 0..32");
     ix->opt_hot = (int)value;
+  } else if (k == "bucket_skip") {
+    ix->opt_no_skip = value == 0;
   } else if (k == "bucket_bits") {
     if (value < 0 || value > 12) return fail(VAQHIP_EINVAL, "bucket_bits must be 0..12");
     ix->opt_bucket_bits = (int)value;  // takes effect when the codes are (re)set
