@@ -295,3 +295,37 @@ def test_gpu_ti_cpp_demo_driver(tmp_path):
     alld = visited_dists(c, ti, 0.2, k)
     d_got = np.take_along_axis(alld, got, axis=1).astype(np.float32)
     assert_topk_matches(got.astype(np.int32), d_got, ol, od, all_dists=alld, what="cpp demo TI")
+
+
+@pytest.mark.gpu
+def test_gpu_ti_full_size_properties():
+    """BASELINE size (1M rows x 8 B, k=100), size-independent properties instead of the oracle:
+    visiting every cluster, TI|EA returns the exhaustive HEAP answer with sqrt'ed distances;
+    visiting fewer, every rank is no better than the exhaustive one and the rows returned
+    really carry the distances reported."""
+    from vaq_amd.index import NNMethod
+    c = ti_case(260, 128, [8] * 8, 1_000_000, 64, 256, 4)
+    nq, k = 64, 100
+    v = _gpu_index(c, methods=NNMethod.Heap)
+    v.mTIClusters = None
+    heap = v.search(c["X"], k, projected=True)
+    hl, hd = heap.labels.reshape(nq, k), heap.distances.reshape(nq, k)
+    v.mTIClusters = c["clusters"]
+    v.mMethods = NNMethod.TI | NNMethod.EA
+    v.mVisit = 1.0
+    a = v.search(c["X"], k, projected=True)
+    al, ad = a.labels.reshape(nq, k), a.distances.reshape(nq, k)
+    assert np.array_equal(ad, np.sqrt(hd))
+    for q in range(nq):  # same rows wherever the sqrt'ed distances are distinct
+        u, cnt = np.unique(ad[q], return_counts=True)
+        single = np.isin(ad[q], u[cnt == 1])
+        assert np.array_equal(al[q][single], hl[q][single])
+    v.mVisit = 0.1
+    b = v.search(c["X"], k, projected=True)
+    bl, bd = b.labels.reshape(nq, k), b.distances.reshape(nq, k)
+    assert np.all(bd >= ad) and np.all(np.diff(bd, axis=1) >= 0) and np.all(bl >= 0)
+    for q in range(0, nq, 8):  # reported distance = the row's own ADC distance
+        lut = po.create_lut(c["X"][q], c["cents"], 8)
+        assert np.array_equal(np.sqrt(po.all_dists(lut, c["codes"][bl[q]])), bd[q])
+        assert len(set(bl[q].tolist())) == k
+    v.close()
