@@ -95,8 +95,9 @@ struct ScanParams {
 
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
                           hipStream_t st);
+// cent_t: the codebooks dimension-major (entry j * ncent + c of subspace s at cent_off)
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,
-                            const SubDesc *sub, const float *cent, int lut_floats, int max_ncent,
+                            const SubDesc *sub, const float *cent_t, int lut_floats, int max_ncent,
                             float *lut, hipStream_t st);
 hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDesc *sub,
                              int lut_floats, int ksub, float *lut_ref, hipStream_t st);

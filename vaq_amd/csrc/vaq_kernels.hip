@@ -96,7 +96,7 @@ __device__ __forceinline__ float sqdiff(float x, float y) {
 
 __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
                                  const SubDesc *__restrict__ sub,
-                                 const float *__restrict__ cent, int lut_floats,
+                                 const float *__restrict__ cent_t, int lut_floats,
                                  float *__restrict__ lut) {
   extern __shared__ float qs[];
   const int q = blockIdx.x, s = blockIdx.y;
@@ -105,51 +105,53 @@ __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
   for (int j = threadIdx.x; j < L; j += blockDim.x) qs[j] = qproj[(size_t)q * D + (size_t)s * L + j];
   __syncthreads();
   float *out = lut + (size_t)q * lut_floats + sd.lut_off;
-  const float *cs = cent + sd.cent_off;
-  // blockIdx.z selects a chunk of 256 centroids, so a 4096-centroid subspace is spread
-  // over 16 workgroups instead of looping in one
-  for (int c = blockIdx.z * blockDim.x + threadIdx.x; c < sd.ncent; c += gridDim.z * blockDim.x) {
-    const float *y = cs + (size_t)c * L;
+  // dimension-major codebook: y(j) of centroid c at cs[j * K + c], so a wave reads 64
+  // consecutive floats per dimension
+  const float *cs = cent_t + sd.cent_off;
+  const int K = sd.ncent;
+#define Y(j) cs[(size_t)(j) * K + c]
+  for (int c = blockIdx.z * blockDim.x + threadIdx.x; c < K; c += gridDim.z * blockDim.x) {
     float r;
-    if (sd.ncent >= 8) {
+    if (K >= 8) {
       float acc = 0.0f;
       for (int j = 0; j < L; j++) {
-        float diff = qs[j] - y[j];
+        float diff = qs[j] - Y(j);
         acc = __builtin_fmaf(diff, diff, acc);
       }
       r = acc;
     } else if (L == 1) {
-      r = sqdiff(qs[0], y[0]);
+      r = sqdiff(qs[0], Y(0));
     } else if (L == 2) {
-      r = sqdiff(qs[0], y[0]) + sqdiff(qs[1], y[1]);
+      r = sqdiff(qs[0], Y(0)) + sqdiff(qs[1], Y(1));
     } else if (L == 4) {
-      r = (sqdiff(qs[0], y[0]) + sqdiff(qs[1], y[1])) + (sqdiff(qs[2], y[2]) + sqdiff(qs[3], y[3]));
+      r = (sqdiff(qs[0], Y(0)) + sqdiff(qs[1], Y(1))) + (sqdiff(qs[2], Y(2)) + sqdiff(qs[3], Y(3)));
     } else if (L == 8) {
-      float a0 = sqdiff(qs[0], y[0]) + sqdiff(qs[4], y[4]);
-      float a1 = sqdiff(qs[1], y[1]) + sqdiff(qs[5], y[5]);
-      float a2 = sqdiff(qs[2], y[2]) + sqdiff(qs[6], y[6]);
-      float a3 = sqdiff(qs[3], y[3]) + sqdiff(qs[7], y[7]);
+      float a0 = sqdiff(qs[0], Y(0)) + sqdiff(qs[4], Y(4));
+      float a1 = sqdiff(qs[1], Y(1)) + sqdiff(qs[5], Y(5));
+      float a2 = sqdiff(qs[2], Y(2)) + sqdiff(qs[6], Y(6));
+      float a3 = sqdiff(qs[3], Y(3)) + sqdiff(qs[7], Y(7));
       r = (a0 + a1) + (a2 + a3);
     } else if (L == 12) {
-      float a0 = (sqdiff(qs[0], y[0]) + sqdiff(qs[4], y[4])) + sqdiff(qs[8], y[8]);
-      float a1 = (sqdiff(qs[1], y[1]) + sqdiff(qs[5], y[5])) + sqdiff(qs[9], y[9]);
-      float a2 = (sqdiff(qs[2], y[2]) + sqdiff(qs[6], y[6])) + sqdiff(qs[10], y[10]);
-      float a3 = (sqdiff(qs[3], y[3]) + sqdiff(qs[7], y[7])) + sqdiff(qs[11], y[11]);
+      float a0 = (sqdiff(qs[0], Y(0)) + sqdiff(qs[4], Y(4))) + sqdiff(qs[8], Y(8));
+      float a1 = (sqdiff(qs[1], Y(1)) + sqdiff(qs[5], Y(5))) + sqdiff(qs[9], Y(9));
+      float a2 = (sqdiff(qs[2], Y(2)) + sqdiff(qs[6], Y(6))) + sqdiff(qs[10], Y(10));
+      float a3 = (sqdiff(qs[3], Y(3)) + sqdiff(qs[7], Y(7))) + sqdiff(qs[11], Y(11));
       r = (a0 + a1) + (a2 + a3);
     } else {
       float res = 0.0f;
       for (int j = 0; j < L; j++) {
-        float t = qs[j] - y[j];
+        float t = qs[j] - Y(j);
         res += t * t;
       }
       r = res;
     }
     out[c] = r;
   }
+#undef Y
 }
 
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L, const SubDesc *sub,
-                            const float *cent, int lut_floats, int max_ncent, float *lut,
+                            const float *cent_t, int lut_floats, int max_ncent, float *lut,
                             hipStream_t st) {
   if (nq == 0) return hipSuccess;
   // one workgroup per (query, subspace): splitting big codebooks over blockIdx.z was measured
@@ -157,7 +159,7 @@ hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L, con
   (void)max_ncent;
   const int chunks = 1;
   hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M, chunks), dim3(256), L * sizeof(float), st, qproj, D, L,
-                     sub, cent, lut_floats, lut);
+                     sub, cent_t, lut_floats, lut);
   return hipGetLastError();
 }
 

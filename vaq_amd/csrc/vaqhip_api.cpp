@@ -76,7 +76,7 @@ struct vaqhip_index {
   int device = 0, n_cu = 256;
   std::vector<int> bits;
   std::vector<vaq::SubDesc> sub;
-  DevBuf d_cent, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
+  DevBuf d_cent, d_cent_t, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
   bool has_eig = false;
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
   int bucket_shift = 0, bucket_t = 0, n_buckets = 1;  // bucketed row order (set with the codes)
@@ -359,7 +359,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
+                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
     if (timing) HIP_TRY(hipEventRecord(ev[2], st));
     vaq::ScanParams sp;
     sp.codes = ix->d_codes.as<uint32_t>();
@@ -607,6 +607,19 @@ int vaqhip_index_create_ex(vaqhip_index **out, int D, int M, const int *bits,
   for (int s = 0; s < M; s++)
     HIP_TRY(hipMemcpy(ix->d_cent.as<float>() + ix->sub[s].cent_off, centroids[s],
                       (size_t)ix->sub[s].ncent * ix->L * sizeof(float), hipMemcpyHostToDevice));
+  {
+    // the same matrices dimension-major (the reference keeps mCentroidsPerSubsCMajor for its
+    // AVX loads, VAQ.cpp:655-660): the LUT build reads them one centroid per lane, coalesced
+    std::vector<float> t((size_t)cent_off);
+    for (int s = 0; s < M; s++) {
+      const int K = ix->sub[s].ncent;
+      for (int c = 0; c < K; c++)
+        for (int j = 0; j < ix->L; j++)
+          t[(size_t)ix->sub[s].cent_off + (size_t)j * K + c] = centroids[s][(size_t)c * ix->L + j];
+    }
+    HIP_TRY(ix->d_cent_t.ensure((size_t)cent_off * sizeof(float)));
+    HIP_TRY(hipMemcpy(ix->d_cent_t.p, t.data(), (size_t)cent_off * sizeof(float), hipMemcpyHostToDevice));
+  }
   HIP_TRY(ix->d_sub.ensure(M * sizeof(vaq::SubDesc)));
   HIP_TRY(hipMemcpy(ix->d_sub.p, ix->sub.data(), M * sizeof(vaq::SubDesc), hipMemcpyHostToDevice));
   HIP_TRY(ix->d_first_sub.ensure(first_sub.size() * sizeof(int)));
@@ -631,7 +644,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
       (void)hipStreamDestroy(ix->stream);
     }
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&ix->d_cent, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
+    for (DevBuf *b : {&ix->d_cent, &ix->d_cent_t, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
                       &ix->d_bstart, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_part_cnt, &ix->w_labels,
                       &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id, &ix->w_order})
@@ -872,7 +885,7 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int project
       qp = ix->w_qproj.as<float>();
     }
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
+                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
     HIP_TRY(vaq::launch_lut_expand(ix->w_lut.as<float>(), n, ix->M, ix->d_sub.as<vaq::SubDesc>(),
                                    ix->lut_floats, ksub, ix->w_lutref.as<float>(), st));
     HIP_TRY(hipMemcpyAsync(lut_out + (size_t)q0 * per_q, ix->w_lutref.p, (size_t)n * per_q * sizeof(float),
