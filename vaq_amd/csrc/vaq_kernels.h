@@ -157,7 +157,8 @@ hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int s
                          const float *cent, const float *d_clusters, int T, uint32_t *d_perm,
                          int *d_start, float *d_xcc_sorted, hipStream_t st);
 // per query: cluster visiting order, the matching distances, clusters visited
-hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters, int T,
+// (clusters_t: the centres dimension-major, T floats per dimension)
+hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters_t, int T,
                           const int *start, int max_visit, int k, int *order, float *qcc, int *nvisit,
                           hipStream_t st);
 // extra LDS bytes of a TI scan workgroup staging `cap` entries of its visiting list

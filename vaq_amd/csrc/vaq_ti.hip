@@ -69,9 +69,15 @@ __device__ __forceinline__ float sq_term(float x, float y) {
 // xs[j * xstride]; the SSE kernels for d in {1,2,4,8,12} reduce their four
 // lanes as (a0 + a1) + (a2 + a3) (two _mm_hadd_ps), everything else is the
 // sequential loop of fvec_L2sqr_ref.
-__device__ __forceinline__ float l2sqr_ref_order(const float *xs, int xstride, const float *__restrict__ y,
-                                                 int d) {
+__device__ __forceinline__ float l2sqr_ref_order(const float *xs, int xstride, const float *__restrict__ yp,
+                                                 int d, int ystride = 1) {
 #define X(j) xs[(j) * xstride]
+  struct YS {
+    const float *p;
+    int st;
+    __device__ __forceinline__ float operator[](int j) const { return p[(size_t)j * st]; }
+  };
+  const YS y{yp, ystride};
   switch (d) {
   case 1: return sq_term(X(0), y[0]);
   case 2: return sq_term(X(0), y[0]) + sq_term(X(1), y[1]);
@@ -251,53 +257,50 @@ hipError_t ti_group_rows(const uint16_t *d_codes, int64_t n, int M, int L, int s
 constexpr int TI_PLAN_THREADS = 256;
 
 __global__ __launch_bounds__(TI_PLAN_THREADS) void ti_plan_kernel(
-    const float *__restrict__ qproj, int D, int d, const float *__restrict__ clusters, int T, int Tp,
+    const float *__restrict__ qproj, int D, int d, const float *__restrict__ clusters_t, int T, int Tp,
     const int *__restrict__ start, int max_visit, int k, int *__restrict__ order,
     float *__restrict__ qcc, int *__restrict__ nvisit) {
   extern __shared__ unsigned char smem[];
-  float *sd = reinterpret_cast<float *>(smem);   // [Tp]
-  int *si = reinterpret_cast<int *>(sd + Tp);    // [Tp]
-  float *qs = reinterpret_cast<float *>(si + Tp);  // [d]
+  // one 64-bit key per cluster: distance bits (>= 0, so they order like the values; NaN sorts
+  // last) above the cluster index -- ascending keys = ascending (distance, cluster)
+  unsigned long long *key = reinterpret_cast<unsigned long long *>(smem);  // [Tp]
+  float *qs = reinterpret_cast<float *>(key + Tp);                         // [d]
   const int q = blockIdx.x, tid = threadIdx.x;
   for (int j = tid; j < d; j += TI_PLAN_THREADS) qs[j] = qproj[(size_t)q * D + j];
   __syncthreads();
   for (int c = tid; c < Tp; c += TI_PLAN_THREADS) {
-    float v = INFINITY;
-    int id = INT_MAX;
+    unsigned long long k = ~0ull;
     if (c < T) {
-      v = sqrtf(l2sqr_ref_order(qs, 1, clusters + (size_t)c * d, d));
-      id = c;
+      // clusters_t is dimension-major (T floats per dimension): lanes read consecutive floats
+      const float v = sqrtf(l2sqr_ref_order(qs, 1, clusters_t + c, d, T));
+      k = ((unsigned long long)__builtin_bit_cast(unsigned, v) << 32) | (unsigned)c;
     }
-    sd[c] = v;
-    si[c] = id;
+    key[c] = k;
   }
   __syncthreads();
-  // bitonic sort of (distance, cluster) pairs, ascending; NaN distances sort last
   for (int size = 2; size <= Tp; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = tid; t < (Tp >> 1); t += TI_PLAN_THREADS) {
         const int i = 2 * t - (t & (stride - 1));
         const int j = i + stride;
-        const float a = sd[i], b = sd[j];
-        const int ia = si[i], ib = si[j];
-        const bool a_nan = a != a, b_nan = b != b;
-        const bool less_ba = a_nan ? (!b_nan || ib < ia) : (!b_nan && (b < a || (b == a && ib < ia)));
-        if (less_ba == ((i & size) == 0)) {
-          sd[i] = b; sd[j] = a;
-          si[i] = ib; si[j] = ia;
+        const unsigned long long a = key[i], b = key[j];
+        if ((a > b) == ((i & size) == 0)) {
+          key[i] = b;
+          key[j] = a;
         }
       }
       __syncthreads();
     }
   for (int i = tid; i < T; i += TI_PLAN_THREADS) {
-    order[(size_t)q * T + i] = si[i];
-    qcc[(size_t)q * T + i] = sd[i];
+    const unsigned long long k = key[i];
+    order[(size_t)q * T + i] = (int)(unsigned)k;
+    qcc[(size_t)q * T + i] = __builtin_bit_cast(float, (unsigned)(k >> 32));
   }
   if (tid == 0) {
     int p = 0;
     int64_t cum = 0;
     while (p < T && cum < k) {
-      const int c = si[p];
+      const int c = (int)(unsigned)key[p];
       cum += start[c + 1] - start[c];
       p++;
     }
@@ -305,14 +308,14 @@ __global__ __launch_bounds__(TI_PLAN_THREADS) void ti_plan_kernel(
   }
 }
 
-hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters, int T,
+hipError_t launch_ti_plan(const float *qproj, int nq, int D, int d, const float *clusters_t, int T,
                           const int *start, int max_visit, int k, int *order, float *qcc, int *nvisit,
                           hipStream_t st) {
   if (nq == 0) return hipSuccess;
   int Tp = 2;
   while (Tp < T) Tp <<= 1;
-  const size_t lds = (size_t)Tp * 8 + (size_t)d * 4;
-  hipLaunchKernelGGL(ti_plan_kernel, dim3(nq), dim3(TI_PLAN_THREADS), lds, st, qproj, D, d, clusters, T, Tp,
+  const size_t lds = (size_t)Tp * 8 + (size_t)d * 4;  // keys + the query's first d dims
+  hipLaunchKernelGGL(ti_plan_kernel, dim3(nq), dim3(TI_PLAN_THREADS), lds, st, qproj, D, d, clusters_t, T, Tp,
                      start, max_visit, k, order, qcc, nvisit);
   return hipGetLastError();
 }

@@ -86,7 +86,7 @@ struct vaqhip_index {
   int ti_T = 0, ti_seg = 0;
   float ti_visit = 1.0f;              // mVisit
   unsigned methods = VAQHIP_METHOD_HEAP;
-  DevBuf d_ti_clusters, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
+  DevBuf d_ti_clusters, d_ti_clusters_t, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
@@ -412,7 +412,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       // VAQ::search's TI branch (VAQ.cpp:799-826) then VAQ::searchTriangleInequality (:1540-1692)
       const int T = ix->ti_T;
       const int max_visit = ix->ti_visit < 1.0f ? (int)((float)T * ix->ti_visit) : T;  // :1548-1551
-      HIP_TRY(vaq::launch_ti_plan(qp, n, ix->D, ix->ti_seg * ix->L, ix->d_ti_clusters.as<float>(), T,
+      HIP_TRY(vaq::launch_ti_plan(qp, n, ix->D, ix->ti_seg * ix->L, ix->d_ti_clusters_t.as<float>(), T,
                                   ix->d_bstart.as<int>(), max_visit, k, ix->w_ti_order.as<int>(),
                                   ix->w_ti_qcc.as<float>(), ix->w_ti_nvisit.as<int>(), st));
       if (timing) HIP_TRY(hipEventRecord(ev[3], st));
@@ -1057,6 +1057,13 @@ int vaqhip_index_set_ti_clusters(vaqhip_index *ix, const float *clusters, int T,
     const size_t bytes = (size_t)T * seg_num * ix->L * sizeof(float);
     HIP_TRY(ix->d_ti_clusters.ensure(bytes));
     HIP_TRY(hipMemcpyAsync(ix->d_ti_clusters.p, clusters, bytes, hipMemcpyHostToDevice, st));
+    // dimension-major copy for the per-query plan (one centre per lane, coalesced)
+    const int dd = seg_num * ix->L;
+    std::vector<float> t((size_t)T * dd);
+    for (int c = 0; c < T; c++)
+      for (int j = 0; j < dd; j++) t[(size_t)j * T + c] = clusters[(size_t)c * dd + j];
+    HIP_TRY(ix->d_ti_clusters_t.ensure(bytes));
+    HIP_TRY(hipMemcpy(ix->d_ti_clusters_t.p, t.data(), bytes, hipMemcpyHostToDevice));
   }
   ix->ti_T = T;
   ix->ti_seg = T > 0 ? seg_num : 0;
