@@ -50,6 +50,7 @@ struct ScanParams {
   int bucket_shift;       // bucket = first code >> bucket_shift
   int bucket_t;           // (bucket_shift == 0) bucket = first code << bucket_t | top bucket_t bits of code 1
   int n_hot;              // buckets a workgroup scans best-first before the rest (0 = off, <= 32)
+  unsigned long long *stats; // diagnostic builds (-DVAQ_STATS): event counters, else nullptr
   int no_skip;            // 1: visit every bucket (measurement only: the streaming rate of the scan)
   const int *first_sub;   // [W+1] first subspace starting in word w (bit-packed layout)
   const float *lut;       // [nq][lut_floats]

@@ -618,6 +618,20 @@ __device__ __forceinline__ float sq_bound(float t) {
   return c;
 }
 
+// VAQ_STATS (diagnostic builds only): per-wave event counts and cycle totals, added into
+// ScanParams::stats at the end of the wave.
+#ifdef VAQ_STATS
+#define STAT_ADD(i, v) cx.st[i] += (unsigned long long)(v)
+#define STAT_T0(name) const unsigned long long name = __builtin_readcyclecounter()
+#define STAT_T1(i, name) cx.st[i] += __builtin_readcyclecounter() - name
+#else
+#define STAT_ADD(i, v)
+#define STAT_T0(name)
+#define STAT_T1(i, name)
+#endif
+enum { ST_STEPS = 0, ST_ALIVE_A, ST_ALIVE_A2, ST_DRAINS, ST_ADMITS, ST_FOLDS, ST_CYC_TOTAL, ST_CYC_ADMIT,
+       ST_CYC_DRAIN, ST_BUCKETS_TESTED, ST_BUCKETS_VISITED, ST_CYC_SETUP, ST_CYC_STEPLOAD, ST_N };
+
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
 // LDS: [LUT][QB x selection state][per wave: survivor queue]
@@ -631,6 +645,9 @@ template <int QB, bool SQ> struct ScanCtx {
   // state and the shared thresholds hold square roots, thr_s caches the threshold itself and
   // thr_d the largest row sum whose square root does not exceed it (for the partial-sum tests)
   static constexpr bool sq = SQ;  // (the TI kernels)
+#ifdef VAQ_STATS
+  unsigned long long st[ST_N];
+#endif
   float thr_s[QB];
   int qi[QB];
   int *q_id;         // survivor queue (wave-private): row id
@@ -985,6 +1002,10 @@ template <int QB, bool SQ> struct ScanCtx {
   __device__ __forceinline__ void admit(const float (&dist)[QB], int srow, bool ok) {
     // cheap pre-test against the cached (never tighter than exact) thresholds
     if (__ballot(ok && survives(dist)) == 0ull) return;
+#ifdef VAQ_STATS
+    const unsigned long long t_adm = __builtin_readcyclecounter();
+    st[ST_ADMITS]++;
+#endif
     const int rid = (ok && survives(dist) && perm) ? (int)perm[srow] : srow;
 #pragma unroll
     for (int q = 0; q < QB; q++) {
@@ -999,6 +1020,9 @@ template <int QB, bool SQ> struct ScanCtx {
       if (m != 0ull) {
         int ncand = (int)v.hdr[SEL_NCAND];
         if (ncand + __popcll(m) > ccap) {
+#ifdef VAQ_STATS
+          st[ST_FOLDS]++;
+#endif
           if (sel_fold(v, k, kp, lane)) {
             td = bits_to_float(v.hdr[SEL_THR_D]);
             ti = (int)v.hdr[SEL_THR_ID];
@@ -1021,6 +1045,9 @@ template <int QB, bool SQ> struct ScanCtx {
       sel_unlock(v, lane);
       set_thr(q, bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(td))));
     }
+#ifdef VAQ_STATS
+    st[ST_CYC_ADMIT] += __builtin_readcyclecounter() - t_adm;
+#endif
   }
 
   // compact the lanes with `alive` set into the survivor queue (NCW code dwords ride along)
@@ -1145,6 +1172,10 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
 
   ScanCtx<QB, TI> cx;
+#ifdef VAQ_STATS
+  for (int i = 0; i < ST_N; i++) cx.st[i] = 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   cx.setup(smem, p, M * 256, qbatch, tid, nthreads);
   if (!TI && EA != EA_NONE) cx.stage_gmin(p, 256, 256, tid, nthreads);
   if (!TI && EA != EA_NONE && cx.n_hot > 0)
@@ -1155,6 +1186,9 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   const int lane = cx.lane, wave = cx.wave;
   __syncthreads();
   cx.refresh(0);  // pick up the seeded / already published thresholds before the first bucket test
+#ifdef VAQ_STATS
+  cx.st[ST_CYC_SETUP] = __builtin_readcyclecounter() - t_begin;
+#endif
 
   const int step_items = nthreads;  // items per workgroup step
   const int64_t item0 = r0 / Item::ROWS + wave * 64 + lane;
@@ -1191,6 +1225,8 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
 
   // phase B: the top n (<= 64) queue entries, one per lane
   auto drain = [&](const int n) {
+    STAT_T0(t_dr);
+    STAT_ADD(ST_DRAINS, 1);
     const int base = cx.qcnt - n;
     const bool ok = lane < n;
     const int slot = base + (ok ? lane : 0);
@@ -1205,6 +1241,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
     for (int i = 1; i < WPR; i++)
       cw[i] = QCW > 0 ? cx.q_cw[(i - 1) * cx.qcap + slot] : codes[(int64_t)rid * WPR + i];
     finish(cw, acc, rid, ok);
+    STAT_T1(ST_CYC_DRAIN, t_dr);
   };
 
   if (EA == EA_NONE) {
@@ -1359,7 +1396,9 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
               l0[q] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lv_get<QB>(l0v, q))));
             }
           }
+          STAT_ADD(ST_BUCKETS_TESTED, 1);
           if (TI || p.no_skip || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
+            STAT_ADD(ST_BUCKETS_VISITED, 1);
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
             Item pf[PREFETCH];
@@ -1371,6 +1410,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 if (TI) xpf[i] = xcc[i == 0 ? pos : base0 + i * WSTEP];
               }
             for (int t = 0; t < nst; t++) {
+              STAT_T0(t_ld);
               const Item cur = pf[0];
               const float xcur =
                   TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
@@ -1384,6 +1424,11 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * WSTEP];
               }
               const int base = base0 + t * WSTEP;
+#ifdef VAQ_STATS
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+              STAT_T1(ST_CYC_STEPLOAD, t_ld);
+              STAT_ADD(ST_STEPS, 1);
               cx.refresh(stepno++);
               if (TI) {
                 // VAQ.cpp:1564-1568: rows of a cluster come farthest from the centre first, so
@@ -1408,8 +1453,10 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 for (int r = 0; r < Item::ROWS; r++) group_sum(cur.word(r, 0), 0, 0, PHASE_A_SUBS, part[r]);
               }
 #pragma unroll
-              for (int r = 0; r < Item::ROWS; r++)
+              for (int r = 0; r < Item::ROWS; r++) {
                 alive[r] = (row0 + r >= pos) && (row0 + r < be) && cx.survives(part[r]);
+                STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
+              }
               // A2 + Q per row
 #pragma unroll
               for (int r = 0; r < Item::ROWS; r++) {
@@ -1418,6 +1465,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                   group_sum(cur.word(r, 0), 0, PHASE_A_SUBS, 4, part[r]);
                   live = cx.survives(part[r]);
                 }
+                STAT_ADD(ST_ALIVE_A2, __popcll(__ballot(live)));
                 if (EA == EA_QUEUE) {
                   uint32_t rest[WPR];
 #pragma unroll
@@ -1440,6 +1488,11 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   }
   if (EA == EA_QUEUE && cx.qcnt > 0) drain(cx.qcnt);
   cx.write_out(p, slice, qbatch);
+#ifdef VAQ_STATS
+  cx.st[ST_CYC_TOTAL] = __builtin_readcyclecounter() - t_begin;
+  if (p.stats && lane == 0)
+    for (int i = 0; i < ST_N; i++) atomicAdd(&p.stats[i], cx.st[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -376,6 +376,13 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bucket_t = ix->bucket_t;
     sp.n_hot = 0;
     sp.no_skip = ix->opt_no_skip;
+    sp.stats = nullptr;
+#ifdef VAQ_STATS
+    static unsigned long long *d_stats = nullptr;
+    if (!d_stats) HIP_TRY(hipMalloc(&d_stats, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
+    sp.stats = d_stats;
+#endif
     sp.lut = ix->w_lut.as<float>();
     sp.lut_floats = ix->lut_floats;
     sp.lds_subs = pl.lds_subs;
@@ -488,6 +495,19 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                 (int64_t)sp.n_buckets <= (int64_t)(ix->layout == vaq::LAYOUT_BYTES ? ix->M * 256 : pl.lut_lds_entries) * pl.qb &&
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+#ifdef VAQ_STATS
+    {
+      unsigned long long h[16];
+      HIP_TRY(hipMemcpyAsync(h, sp.stats, sizeof h, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const double w = (double)grid * sp.nwaves;
+      std::fprintf(stderr,
+                   "[VAQ_STATS] per wave: steps %.1f alive_A %.1f alive_A2 %.1f drains %.2f admits %.2f folds %.2f "
+                   "buckets tested %.1f visited %.1f | cycles total %.0f setup %.0f stepload-wait %.0f admit %.0f drain %.0f\n",
+                   h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[9] / w, h[10] / w, h[6] / w, h[11] / w,
+                   h[12] / w, h[7] / w, h[8] / w);
+    }
+#endif
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
     const int lists = ix->N > 0 ? pl.n_slices : 0;
     if (!direct)
