@@ -1412,6 +1412,10 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
             for (int t = 0; t < nst; t++) {
               STAT_T0(t_ld);
               const Item cur = pf[0];
+#ifdef VAQ_STATS
+              asm volatile("" ::"v"(cur.w[0].x));  // the wait for this step's item lands here
+              STAT_T1(ST_CYC_STEPLOAD, t_ld);
+#endif
               const float xcur =
                   TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
 #pragma unroll
@@ -1424,10 +1428,6 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * WSTEP];
               }
               const int base = base0 + t * WSTEP;
-#ifdef VAQ_STATS
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-              STAT_T1(ST_CYC_STEPLOAD, t_ld);
               STAT_ADD(ST_STEPS, 1);
               cx.refresh(stepno++);
               if (TI) {
