@@ -12,10 +12,14 @@ Workloads (BASELINE.json configs):
       (the configuration the metric is quoted on; default)
   c3  same data, non-uniform bits {12,10,9,8,8,7,6,4}
   c5  1B x 128, 16 x 256 (uniform-random codes unless --encode; --rows scales it)
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the code rows
-are sharded contiguously across ranks, every rank answers all
-queries on its shard, and one RCCL all-gather of the per-shard top-k plus a
-merge kernel finishes the step: total work is fixed -> "scaling": "strong".
+For N > 1 (launched by torch.distributed.run, one rank per GPU):
+  --scaling weak (default for c2/c3, whose codes fit every GPU): the index is replicated,
+      each GPU answers its OWN batch of nq queries, results stay on the GPU that owns the
+      queries -- independent units, no data-path collective; value = N * nq * K / time.
+  --scaling strong (default for c5): total work fixed.  --shard rows: the code rows are
+      sharded contiguously across ranks, every rank answers all queries on its
+      shard, one RCCL all-gather of the per-shard top-k plus a merge kernel finishes the step;
+      --shard queries: codes replicated, the nq queries split across ranks, one all-gather.
 
 Prints ONE JSON line on rank 0.
 """
@@ -62,6 +66,9 @@ def parse():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N > 1: weak = every GPU its own nq queries on a replicated index (default c2/c3); "
+                         "strong = the same nq queries and rows split over the GPUs (default c5)")
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "queries"],
                     help="multi-GPU: shard code rows (all-gather + merge), or replicate codes and shard queries")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
@@ -118,7 +125,8 @@ def main():
     # ---------------------------------------------------------------- setup --
     t_setup = time.time()
     code_bytes_est = (sum(bits) + 7) // 8
-    mode = sharding.choose_mode(N, code_bytes_est, nq, world, args.shard)
+    weak = world > 1 and (args.scaling == "weak" or (args.scaling == "auto" and args.workload != "c5"))
+    mode = "queries" if weak else sharding.choose_mode(N, code_bytes_est, nq, world, args.shard)
     if mode == "rows":
         lo, hi = sharding.shard_bounds(N, world, rank)
     else:
@@ -195,15 +203,16 @@ def main():
     v.mCodebook = codes
     v._ensure_codes()
     host_codes = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and world == 1:
         n_cpu_rows = min(n_local, 1_000_000 if args.workload != "c5" else 4_000_000)
         host_codes = codes[:n_cpu_rows].cpu().numpy().view(np.uint16)
     del codes
     v.mCodebook = None  # packed copy lives in the index; keep _codes_sig
     torch.cuda.empty_cache()
 
-    queries = harness.sift_like(nq, D, stream=7, device=dev)
-    q_lo, q_hi = (0, nq) if mode == "rows" else sharding.shard_bounds(nq, world, rank)
+    # weak scaling: every rank draws its own query batch (disjoint generator streams)
+    queries = harness.sift_like(nq, D, stream=7 + (100 * rank if weak else 0), device=dev)
+    q_lo, q_hi = (0, nq) if (mode == "rows" or weak) else sharding.shard_bounds(nq, world, rank)
     my_queries = queries[q_lo:q_hi].contiguous()
     nq_local = q_hi - q_lo
     if args.qb:
@@ -226,20 +235,20 @@ def main():
     # every buffer of the steady-state loop is allocated once, here; with several ranks the
     # labels and distances of a rank travel in ONE all-gather (packed [2, n, k] int32 buffer)
     per_q = (nq + world - 1) // world
-    n_pack = nq if mode == "rows" else per_q
+    n_pack = nq if (mode == "rows" or weak) else per_q
     pack_local, lab_view, dis_view = sharding.make_packed(n_pack, k, dev)
     out_local = (lab_view[:nq_local], dis_view[:nq_local])
     if nq_local < n_pack:  # short last query slice: the padding rows stay empty
         lab_view[nq_local:].fill_(-1)
         dis_view[nq_local:].fill_(3.4028234663852886e38)
-    gathered = torch.empty((world, 2, n_pack, k), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.empty((world, 2, n_pack, k), dtype=torch.int32, device=dev) if (world > 1 and not weak) else None
     out_final = (torch.empty((nq, k), dtype=torch.int32, device=dev),
-                 torch.empty((nq, k), dtype=torch.float32, device=dev)) if world > 1 else None
+                 torch.empty((nq, k), dtype=torch.float32, device=dev)) if (world > 1 and not weak) else None
     from vaq_amd.index import merge_topk_packed_device
 
     def run_step():
         l, d = v.search_device(my_queries, k, out=out_local)
-        if world > 1:
+        if world > 1 and not weak:
             sharding.all_gather_packed(pack_local, gathered)
             if mode == "rows":
                 l, d = merge_topk_packed_device(gathered, world, nq, k, out=out_final)
@@ -285,7 +294,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    qps = nq * args.steps / elapsed
+    nq_total = nq * world if weak else nq
+    qps = nq_total * args.steps / elapsed
 
     # ------------------------------------------------------------- roofline --
     # unit = one database row scanned in one pass; bytes = ceil(sum bits / 8);
@@ -334,7 +344,9 @@ def main():
 
     # --------------------------------------------------------- cpu baseline --
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    # (rank 0 at N = 1 only: with several ranks on the box the host cores are shared with their
+    #  runtime threads and the other ranks would sit in a barrier for the duration)
+    if rank == 0 and not args.no_cpu and world == 1:
         from oracle import pyoracle as po
         po.build(ref=False)
         threads = max(1, min(po.max_threads(), os.cpu_count() or 1))
@@ -401,13 +413,17 @@ def main():
             "metric": "queries/sec (ADC search, recall@100 reported alongside)",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq, "k": k,
+            "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq_total,
+                       "queries_per_gpu": nq if (weak or world == 1) else (nq if mode == "rows" else per_q), "k": k,
                        "bits": bits, "code_bytes": info["algo_code_bytes"],
                        "codes": "encoded" if real_codes else "uniform-random",
                        "method": ("EA_TI%dm%d visit=%g (k-means centres over decoded codes)" % (ti_T, ti_seg, args.visit))
                        if args.ti else "HEAP/EA (exhaustive)",
                        "sharding": "none" if world == 1 else (
+                           "weak: index replicated on every GPU, each GPU answers its own batch of queries, "
+                           "results stay with their owner (no data-path collective)" if weak else
                            "rows: contiguous shards, RCCL all-gather of per-shard top-k + merge" if mode == "rows"
                            else "queries: codes replicated (fit HBM), disjoint query slices, RCCL all-gather of results")},
             "roofline": roofline, "cpu_baseline": cpu, "recall": recall,
