@@ -630,7 +630,8 @@ __device__ __forceinline__ float sq_bound(float t) {
 #define STAT_T1(i, name)
 #endif
 enum { ST_STEPS = 0, ST_ALIVE_A, ST_ALIVE_A2, ST_DRAINS, ST_ADMITS, ST_FOLDS, ST_CYC_TOTAL, ST_CYC_ADMIT,
-       ST_CYC_DRAIN, ST_BUCKETS_TESTED, ST_BUCKETS_VISITED, ST_CYC_SETUP, ST_CYC_STEPLOAD, ST_N };
+       ST_CYC_DRAIN, ST_BUCKETS_TESTED, ST_BUCKETS_VISITED, ST_CYC_SETUP, ST_CYC_STEPLOAD, ST_CYC_FOLD,
+       ST_CYC_LOCKWAIT, ST_N };
 
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.
@@ -1012,7 +1013,13 @@ template <int QB, bool SQ> struct ScanCtx {
       if (__ballot(ok && !(dist[q] > thr_d[q])) == 0ull) continue;
       const float dq = sq ? sqrtf(dist[q]) : dist[q];
       const SelView &v = sel[q];
+#ifdef VAQ_STATS
+      const unsigned long long t_lock = __builtin_readcyclecounter();
+#endif
       sel_lock(v, lane);
+#ifdef VAQ_STATS
+      st[ST_CYC_LOCKWAIT] += __builtin_readcyclecounter() - t_lock;
+#endif
       float td = bits_to_float(v.hdr[SEL_THR_D]);
       int ti = (int)v.hdr[SEL_THR_ID];
       bool pass = ok && pair_less(dq, rid, td, ti);
@@ -1022,8 +1029,13 @@ template <int QB, bool SQ> struct ScanCtx {
         if (ncand + __popcll(m) > ccap) {
 #ifdef VAQ_STATS
           st[ST_FOLDS]++;
-#endif
+          const unsigned long long t_fold = __builtin_readcyclecounter();
+          const bool moved_ = sel_fold(v, k, kp, lane);
+          st[ST_CYC_FOLD] += __builtin_readcyclecounter() - t_fold;
+          if (moved_) {
+#else
           if (sel_fold(v, k, kp, lane)) {
+#endif
             td = bits_to_float(v.hdr[SEL_THR_D]);
             ti = (int)v.hdr[SEL_THR_ID];
             if (multi_slice && lane == 0) atomicMin(&g_thr[qi[q]], float_to_bits(td));

@@ -503,9 +503,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       const double w = (double)grid * sp.nwaves;
       std::fprintf(stderr,
                    "[VAQ_STATS] per wave: steps %.1f alive_A %.1f alive_A2 %.1f drains %.2f admits %.2f folds %.2f "
-                   "buckets tested %.1f visited %.1f | cycles total %.0f setup %.0f stepload-wait %.0f admit %.0f drain %.0f\n",
+                   "buckets tested %.1f visited %.1f | cycles total %.0f setup %.0f stepload-wait %.0f admit %.0f "
+                   "(fold %.0f lock-wait %.0f) drain %.0f\n",
                    h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[9] / w, h[10] / w, h[6] / w, h[11] / w,
-                   h[12] / w, h[7] / w, h[8] / w);
+                   h[12] / w, h[7] / w, h[13] / w, h[14] / w, h[8] / w);
     }
 #endif
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
