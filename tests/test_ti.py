@@ -329,3 +329,31 @@ def test_gpu_ti_full_size_properties():
         assert np.array_equal(np.sqrt(po.all_dists(lut, c["codes"][bl[q]])), bd[q])
         assert len(set(bl[q].tolist())) == k
     v.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ti_append_and_method_errors():
+    """Rows appended to a TI-grouped index are regrouped with the rest; set_method rejects
+    the methods that are not on this path."""
+    import ctypes as C
+    from vaq_amd import _lib
+    c = ti_case(270, 64, [8] * 8, 12000, 6, 40, 4)
+    ti = po.cluster_ti(c["codes"], c["cents"], c["clusters"], 4)
+    v = _gpu_index(dict(c, codes=c["codes"][:5000]), visit=0.3)
+    k = 20
+    v.search(c["X"], k, projected=True)
+    v.add_codes(c["codes"][5000:])
+    ans = v.search(c["X"], k, projected=True)
+    ol, od, _ = po.search_ti(c["X"], c["cents"], ti, k, visit=0.3, projected=True)
+    assert_topk_matches(ans.labels.reshape(6, k), ans.distances.reshape(6, k), ol, od, what="TI append")
+    L = _lib.load()
+    assert L.vaqhip_index_set_method(v._h, 0x08, C.c_float(1.0)) == -2      # FAST
+    assert L.vaqhip_index_set_method(v._h, 0x01, C.c_float(1.0)) == -2      # SORT
+    assert L.vaqhip_index_set_method(v._h, 0x06, C.c_float(0.0)) == -1      # visit must be > 0
+    assert L.vaqhip_index_set_method(v._h, 0x80, C.c_float(1.0)) == 0       # HEAP on a TI-grouped index ...
+    lab = np.empty((6, k), np.int32)
+    dis = np.empty((6, k), np.float32)
+    rc = L.vaqhip_search_projected(v._h, c["X"].ctypes.data_as(C.c_void_p), 6, k,
+                                   lab.ctypes.data_as(C.c_void_p), dis.ctypes.data_as(C.c_void_p))
+    assert rc == -7 and b"TI" in L.vaqhip_last_error()                      # ... is a state error at search
+    v.close()
