@@ -13,14 +13,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vaq_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "vaq_amd", "lib")
 LIB = os.path.join(LIBDIR, "libvaqhip.so")
-SOURCES = ["vaq_kernels.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
+SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
 KERNEL_HEADER = os.path.join(CSRC, "vaq_kernels.h")
 API_HEADER = os.path.join(ROOT, "include", "vaqhip.h")
 
 
+SCAN_HEADER = os.path.join(CSRC, "vaq_scan.h")
+
+
 def _deps(src: str):
-    # only the host file sees the public C header
-    return [os.path.join(CSRC, src), KERNEL_HEADER] + ([API_HEADER] if src.endswith(".cpp") else [])
+    # only the host file sees the public C header; the scan bodies live in vaq_scan.h
+    deps = [os.path.join(CSRC, src), KERNEL_HEADER]
+    if src.endswith(".cpp"):
+        deps.append(API_HEADER)
+    if src in ("vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip"):
+        deps.append(SCAN_HEADER)
+    return deps
 OBJDIR = os.path.join(LIBDIR, "obj")
 
 
