@@ -141,7 +141,11 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   // ... and 1 as well for byte codes that stay cache-resident (<= 128 MB): sharing the code
   // stream between two queries buys nothing there, per-query bucket skipping does
   const bool resident = (double)ix->N * ((ix->total_bits + 7) / 8) <= 128e6;
-  int qb = ix->opt_qb > 0 ? ix->opt_qb : ((ix->layout == vaq::LAYOUT_BYTES && !resident) ? 2 : 1);
+  // ... and 4 for a streamed (non-resident) byte-coded database once there are enough queries to
+  // fill the passes (250M x 16 B: 256 queries 18.4 -> 15.4 ms, 32 queries 3.6 -> 3.4 ms; no gain
+  // below)
+  int qb = ix->opt_qb > 0 ? ix->opt_qb
+                          : ((ix->layout == vaq::LAYOUT_BYTES && !resident) ? (nq >= 32 ? 4 : 2) : 1);
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
   // the selection state are per workgroup, the survivor queues per wave; a CU
