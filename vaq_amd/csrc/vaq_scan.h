@@ -129,9 +129,15 @@ __device__ __forceinline__ SelView sel_view(unsigned char *base, int kp, int cca
 __device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 
+// (The spin is wave-uniform: only lane 0 tries the lock, but every lane goes round the loop.
+//  A spin under `if (lane == 0)` is not a reconvergence point the compiler has to respect --
+//  a prototype with such a spin inside a retry loop had lanes 1..63 run ahead of lane 0.)
 __device__ __forceinline__ void sel_lock(const SelView &v, int lane) {
-  if (lane == 0) {
-    while (atomicCAS(&v.hdr[SEL_LOCK], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+  for (;;) {
+    unsigned held = 1u;
+    if (lane == 0) held = atomicCAS(&v.hdr[SEL_LOCK], 0u, 1u);
+    if (__builtin_amdgcn_readfirstlane((int)held) == 0) break;
+    __builtin_amdgcn_s_sleep(1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
