@@ -223,7 +223,10 @@ constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 #endif
 constexpr int PREFETCH = VAQ_PREFETCH;  // items loaded ahead of the one being processed
 constexpr int PHASE_A_SUBS = 2;    // subspaces summed before the first survivor test
-constexpr int THR_LOCAL_EVERY = 8; // steps between reads of the workgroup threshold
+#ifndef VAQ_THR_EVERY
+#define VAQ_THR_EVERY 8
+#endif
+constexpr int THR_LOCAL_EVERY = VAQ_THR_EVERY; // steps between reads of the workgroup threshold
 constexpr int THR_GLOBAL_EVERY = 64;
 #ifndef VAQ_HOT_MAX
 #define VAQ_HOT_MAX 32
