@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- queries/sec of the VAQ ADC search path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|c2|c3|c4|c5]
 
 One "step" = one pass of the hot path (project -> LUT build -> code scan with
-top-k -> merge [-> all-gather + merge across GPUs]) over one batch of nq
+top-k -> merge [-> RCCL all-gather + merge across GPUs]) over one batch of nq
 synthetic queries that are already resident in HBM, results left in HBM.
 
 Workloads (BASELINE.json configs):
   c2  SIFT-1M-shaped, d=128, 8 subspaces x 256 centroids, 10k queries, k=100
-      (the configuration the metric is quoted on; default)
+      (the configuration the metric is quoted on; the N = 1 default)
   c3  same data, non-uniform bits {12,10,9,8,8,7,6,4}
-  c5  1B x 128, 16 x 256 (uniform-random codes unless --encode; --rows scales it)
-For N > 1 (launched by torch.distributed.run, one rank per GPU):
-  --scaling weak (default for c2/c3, whose codes fit every GPU): the index is replicated,
-      each GPU answers its OWN batch of nq queries, results stay on the GPU that owns the
-      queries -- independent units, no data-path collective; value = N * nq * K / time.
-  --scaling strong (default for c5): total work fixed.  --shard rows: the code rows are
-      sharded contiguously across ranks, every rank answers all queries on its
-      shard, one RCCL all-gather of the per-shard top-k plus a merge kernel finishes the step;
-      --shard queries: codes replicated, the nq queries split across ranks, one all-gather.
+  c4  100M x 128, 8 x 256, 10k queries
+  c5  1B x 128, 16 x 256, 10k queries (the N > 1 default; --rows scales it)
+
+N = 1 (default invocation): `value` is the c2 rate.  c2's code array (8 MB) lives in
+cache and most of it is pruned unread, so its scan kernel has no HBM roofline; the
+`roofline` object is therefore measured, in the same process, on the one launch of this
+path that IS an HBM stream: a single pass over 1B x 16 B of encoded codes with every
+bucket visited (`roofline.workload` names it; --no-c5-leg skips it and leaves
+`roofline` to the counter-based description of the c2 kernel alone).  The same leg
+times the N > 1 default workload on one GPU (`scale_base`), so the per-N lines of a
+scaling run have their one-GPU reference.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the north-star path --
+strong scaling, the code rows sharded contiguously across the ranks, every
+rank answers all queries on its shard, one RCCL all-gather of the per-shard top-k and a
+merge kernel finish the step.  `--shard queries` replicates the codes and splits the
+queries instead; `--scaling replicas` runs N independent replicas (no collective,
+labelled as such).
 
 Prints ONE JSON line on rank 0.
 """
@@ -38,6 +47,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GEN = 1 << 20           # rows per generated chunk; chunk c is the same on every rank layout
+D = 128
 
 
 def parse():
@@ -45,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "c4", "c5"])
     ap.add_argument("--rows", type=int, default=0, help="override database rows (total)")
     ap.add_argument("--nq", type=int, default=0, help="override queries per step")
     ap.add_argument("--k", type=int, default=100)
@@ -62,15 +73,21 @@ def parse():
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
     ap.add_argument("--no-skip", action="store_true", help="visit every bucket (streaming-rate measurement)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="bits of the first code that key the row buckets (0 = auto)")
-    ap.add_argument("--encode", action="store_true", help="c5: encode real vectors instead of random codes")
+    ap.add_argument("--random-codes", action="store_true", help="uniform-random codes instead of encoded vectors")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
-                    help="N > 1: weak = every GPU its own nq queries on a replicated index (default c2/c3); "
-                         "strong = the same nq queries and rows split over the GPUs (default c5)")
+    ap.add_argument("--parity-queries", type=int, default=256,
+                    help="queries of the timed result checked against the CPU oracle (N = 1, c2/c3)")
+    ap.add_argument("--no-c5-leg", action="store_true",
+                    help="N = 1 default run: skip the in-process 1B x 16 B roofline / scale_base leg")
+    ap.add_argument("--c5-rows", type=int, default=1_000_000_000, help="rows of that leg (rehearsals)")
+    ap.add_argument("--c5-launches", type=int, default=12)
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "replicas", "weak"],
+                    help="N > 1: strong (default) = the same queries, rows (or queries) split over the GPUs; "
+                         "replicas (alias weak) = every GPU its own nq queries on a replicated index, no collective")
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "queries"],
-                    help="multi-GPU: shard code rows (all-gather + merge), or replicate codes and shard queries")
+                    help="multi-GPU: shard code rows (all-gather + merge; default), or replicate codes and shard queries")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
@@ -79,6 +96,220 @@ def parse():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def base_chunk(c, N, dev):
+    from vaq_amd import harness
+    m = min(GEN, N - c * GEN)
+    return harness.sift_like(m, D, stream=1000 + c, device=dev)
+
+
+def build_index(bits, N, lo, hi, dev, device_index, world, rank, iters, random_codes=False, ti=None,
+                bucket_bits=0, keep_host_rows=0):
+    """Train (harness: PCA + k-means on the first chunk; rank 0's state is broadcast), encode
+    rows [lo, hi) with the product's own encoder and hand them to a VaqHip index.
+    Returns (index, host uint16 copy of the first keep_host_rows rows or None, cents, ti info)."""
+    import torch.distributed as dist
+    import vaq_amd
+    from vaq_amd import harness
+    M = len(bits)
+    n_local = hi - lo
+    train = base_chunk(0, N, dev)[: min(N, 262144)]
+    eig = harness.pca_eigenvectors(train).to(dev)
+    if world > 1:
+        dist.broadcast(eig, 0)
+    tp = train @ eig
+    cents = harness.train_codebooks(tp, bits, iters=iters)
+    if world > 1:
+        for s in range(M):
+            t = torch.from_numpy(cents[s]).to(dev)
+            dist.broadcast(t, 0)
+            cents[s] = t.cpu().numpy()
+    del tp, train
+
+    v = vaq_amd.VaqHip(device=device_index)
+    v.parseMethodString("VAQ%dm%dmin%dmax%dvar1,HEAP" % (sum(bits), M, min(bits), max(bits)))
+    v.mBitsAlloc = list(bits)
+    v.mCentroidsPerSubs = cents
+    v.mEigenVectors = eig.cpu().numpy()
+    v.id_base = lo
+
+    codes = torch.empty((n_local, M), dtype=torch.int16, device=dev)
+    if not random_codes:
+        c0, c1 = lo // GEN, ((hi + GEN - 1) // GEN if hi > lo else lo // GEN)
+        for c in range(c0, c1):
+            X = base_chunk(c, N, dev)
+            a, b = max(lo, c * GEN), min(hi, (c + 1) * GEN)
+            xs = X[a - c * GEN: b - c * GEN]
+            # the product's own encoder (VAQ::encode on the GPU; projects with eig first)
+            codes[a - lo: b - lo] = v.encode_device(xs.contiguous(), projected=False)
+            del X, xs
+    else:
+        g = torch.Generator(device=dev).manual_seed(harness.SEED + rank)
+        step_rows = 1 << 24
+        for r in range(0, n_local, step_rows):
+            m = min(step_rows, n_local - r)
+            codes[r: r + m] = torch.randint(0, 256, (m, M), generator=g, device=dev, dtype=torch.int16)
+    ti_info = (0, 0)
+    if ti:
+        # VAQ::clusterTI: centres = k-means over decoded code rows (at most 256 per centre, as
+        # KMeans::staticFitCodebook samples, KMeans.hpp:618-650); training, so it runs in the harness
+        ti_T, ti_seg, visit = ti
+        ti_seg = ti_seg or M
+        g = torch.Generator(device="cpu").manual_seed(harness.SEED)
+        pick = torch.randperm(n_local, generator=g)[: min(n_local, 256 * ti_T)].to(dev)
+        samp = codes[pick].to(torch.int64) & 0xffff
+        dec = torch.cat([torch.from_numpy(cents[s]).to(dev)[samp[:, s]] for s in range(ti_seg)], dim=1)
+        cl = harness.kmeans(dec, ti_T, iters=25, seed=harness.SEED)
+        if world > 1:
+            dist.broadcast(cl, 0)
+        v.mTIClusters = cl.cpu().numpy()
+        v.mTISegmentNum = ti_seg
+        v.mTIClusterNum = ti_T
+        v.mMethods = vaq_amd.NNMethod.TI | vaq_amd.NNMethod.EA
+        v.mVisit = visit
+        ti_info = (ti_T, ti_seg)
+        del dec, samp, pick
+    if bucket_bits:
+        v._ensure_index()
+        v.set_option("bucket_bits", bucket_bits)
+    v.mCodebook = codes
+    v._ensure_codes()
+    host_codes = None
+    if keep_host_rows > 0:
+        host_codes = codes[: min(n_local, keep_host_rows)].cpu().numpy().view(np.uint16)
+    del codes
+    v.mCodebook = None  # the packed copy lives in the index
+    torch.cuda.empty_cache()
+    return v, host_codes, cents, ti_info
+
+
+def settle(run_step, seconds=0.3):
+    """Part of setup, untimed: the index build frees several GB of staging memory and the
+    driver reclaims it asynchronously -- a one-off 40-60 ms stall of the GPU queue lands some
+    milliseconds later (tools/step_times.py; INTEGRATION.md "first search after set_codes").
+    Run the step until `seconds` have passed so that it is not mistaken for a step time."""
+    t = time.perf_counter()
+    while time.perf_counter() - t < seconds:
+        run_step()
+        torch.cuda.synchronize()
+
+
+def scan_kernel_name(info, tm, ti=False, no_skip=False):
+    """Name rocprofv3 lists the scan kernel of this plan under (vaq_scan_bytes.hip / _bits.hip)."""
+    if ti:
+        return "scan_%s_ti_kernel" % ("bytes" if info["layout"] == 0 else "bits")
+    if info["layout"] == 0:
+        if tm["early_abandon"] == 2:
+            return "scan_bytes_inplace_kernel<%d, %d, %s>" % (info["M"], tm["queries_per_pass"],
+                                                              "true" if no_skip else "false")
+        return "scan_bytes_kernel<%d, %d, %d>" % (info["M"], tm["queries_per_pass"], tm["early_abandon"])
+    return "scan_bits_kernel (W=%d, Qb=%d, ea=%d)" % ((info["total_bits"] + 31) // 32, tm["queries_per_pass"],
+                                                       tm["early_abandon"])
+
+
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return {}
+
+
+def c5_leg(args, dev, device_index, k):
+    """N = 1 default run: the HBM roofline of the path, measured in this process.
+    (1) one pass over c5_rows x 16 B of encoded codes, every bucket visited (bucket_skip = 0,
+        Qb = 2, 2 queries, no pre-pass): the launch whose algorithmic bytes all cross HBM;
+    (2) the same 2 queries in the default mode (bucket skipping + threshold pre-pass);
+    (3) the N > 1 default workload (c5, all its queries) on this one GPU: `scale_base`."""
+    from vaq_amd import harness
+    bits = [8] * 16
+    N = args.c5_rows
+    t0 = time.time()
+    v, _, _, _ = build_index(bits, N, 0, N, dev, device_index, 1, 0, iters=8)
+    info = v.info()
+    build_s = time.time() - t0
+    log(f"[c5 leg] index of {N} rows built in {build_s:.1f}s")
+    nq_full = 10_000
+    queries = harness.sift_like(nq_full, D, stream=7, device=dev)
+    q2 = queries[:2].contiguous()
+    out2 = (torch.empty((2, k), dtype=torch.int32, device=dev), torch.empty((2, k), dtype=torch.float32, device=dev))
+
+    def timed(fn, launches, warm):
+        settle(fn)
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        v.set_option("timing", 1)
+        v.last_timing()
+        t = time.perf_counter()
+        for _ in range(launches):
+            fn()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t) / launches * 1e3
+        tm = v.last_timing()
+        v.set_option("timing", 0)
+        return tm, wall
+
+    # (1) streaming pass
+    v.set_option("queries_per_pass", 2)
+    v.set_option("seed_thresholds", 0)
+    v.set_option("bucket_skip", 0)
+    tm, wall = timed(lambda: v.search_device(q2, k, out=out2), args.c5_launches, 3)
+    stream_labels = out2[0].clone()
+    stream_dists = out2[1].clone()
+    algo = float(N) * info["algo_code_bytes"] * tm["passes"]
+    achieved = algo / (tm["scan_ms"] * 1e-3) / 1e9
+    kname = scan_kernel_name(info, tm, no_skip=True)
+    roof = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "workload": "synthetic %dx128 m16x256 (encoded), ONE pass: 2 queries, Qb=2, every bucket visited "
+                    "(bucket_skip=0), no pre-pass" % N,
+        "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
+        "wall_ms_per_launch": round(wall, 4), "queries_per_pass": tm["queries_per_pass"], "passes": tm["passes"],
+        "rows": N, "code_bytes": info["algo_code_bytes"], "algorithmic_bytes_per_launch": algo,
+        "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
+        "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
+                             "merge": round(tm["merge_ms"], 4)},
+        "index_build_s": round(build_s, 1),
+    }
+    tr = load_profile_json("r02_traffic.json").get("c5_stream")
+    if tr and tr.get("rows") == N and tr.get("kernel") == kname:
+        roof["traffic"] = tr["hbm_bytes_per_launch"]
+        roof["traffic_source"] = tr["source"]
+
+    # (2) the same two queries, default mode
+    v.set_option("queries_per_pass", 0)
+    v.set_option("seed_thresholds", 1)
+    v.set_option("bucket_skip", 1)
+    tm2, wall2 = timed(lambda: v.search_device(q2, k, out=out2), args.c5_launches, 3)
+    same = bool(torch.equal(out2[0], stream_labels) and torch.equal(out2[1], stream_dists))
+    roof["default_mode"] = {
+        "what": "same 2 queries with bucket skipping and the threshold pre-pass on (the library's defaults)",
+        "kernel": scan_kernel_name(info, tm2), "kernel_ms": round(tm2["scan_ms"], 4),
+        "pre_pass_ms": round(tm2["seed_ms"], 4), "merge_ms": round(tm2["merge_ms"], 4),
+        "wall_ms_per_launch": round(wall2, 4), "queries_per_s": round(2 / (wall2 * 1e-3), 1),
+        "results_identical_to_streaming_pass": same,
+    }
+    assert same, "c5 leg: the streaming pass and the default mode disagree"
+
+    # (3) the N > 1 default workload on one GPU
+    outf = (torch.empty((nq_full, k), dtype=torch.int32, device=dev),
+            torch.empty((nq_full, k), dtype=torch.float32, device=dev))
+    tm3, wall3 = timed(lambda: v.search_device(queries, k, out=outf), 2, 1)
+    scale_base = {
+        "workload": "synthetic %dx128 m16x256 nq10k k100 (the N > 1 default), 1 GPU" % N,
+        "value": round(nq_full / (wall3 * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(wall3, 3),
+        "steps": 2, "kernel": scan_kernel_name(info, tm3), "kernel_ms": round(tm3["scan_ms"], 3),
+        "pre_pass_ms": round(tm3["seed_ms"], 3), "merge_ms": round(tm3["merge_ms"], 3),
+        "queries_per_pass": tm3["queries_per_pass"], "passes": tm3["passes"],
+    }
+    assert bool(torch.equal(outf[0][:2], stream_labels) and torch.equal(outf[1][:2], stream_dists)), \
+        "c5 leg: the 10k-query batch and the streaming pass disagree on the first two queries"
+    v.close()
+    del v
+    torch.cuda.empty_cache()
+    return roof, scale_base
 
 
 def main():
@@ -104,115 +335,39 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    import vaq_amd
+    import vaq_amd  # noqa: F401
     from vaq_amd import build, harness, sharding
-    from vaq_amd.index import merge_topk_device
+    from vaq_amd.index import merge_topk_packed_device
     build.build_lib()
 
-    D, k = 128, args.k
-    if args.workload == "c2":
-        bits, N, nq, name = [8] * 8, 1_000_000, 10_000, "sift1m-shaped d128 m8x256 nq10k k100"
-    elif args.workload == "c3":
-        bits, N, nq, name = list(harness.C3_BITS), 1_000_000, 10_000, "sift1m-shaped d128 bits{12,10,9,8,8,7,6,4} nq10k k100"
-    else:
-        bits, N, nq, name = [8] * 16, 1_000_000_000, 256, "synthetic 1Bx128 m16x256 k100"
-    if args.rows:
-        N = args.rows
-    if args.nq:
-        nq = args.nq
+    k = args.k
+    plan = sharding.bench_plan(world, args.workload, args.scaling, args.shard, rows=args.rows, nq=args.nq)
+    wl, N, nq, bits, name = plan["workload"], plan["rows"], plan["nq"], plan["bits"], plan["name"]
+    replicas, mode = plan["replicas"], plan["mode"]
     M = len(bits)
 
     # ---------------------------------------------------------------- setup --
     t_setup = time.time()
-    code_bytes_est = (sum(bits) + 7) // 8
-    weak = world > 1 and (args.scaling == "weak" or (args.scaling == "auto" and args.workload != "c5"))
-    mode = "queries" if weak else sharding.choose_mode(N, code_bytes_est, nq, world, args.shard)
     if mode == "rows":
         lo, hi = sharding.shard_bounds(N, world, rank)
     else:
         lo, hi = 0, N
-    shard = hi - lo if mode == "queries" else (N + world - 1) // world
     n_local = hi - lo
-    GEN = 1 << 20  # rows per generated chunk; chunk c is the same on every rank layout
-
-    def base_chunk(c):
-        m = min(GEN, N - c * GEN)
-        return harness.sift_like(m, D, stream=1000 + c, device=dev)
-
-    real_codes = args.workload != "c5" or args.encode
-    # train on the first chunk (every rank derives identical state; rank 0's is broadcast)
-    train = base_chunk(0)[: min(N, 262144)]
-    eig = harness.pca_eigenvectors(train).to(dev)
-    if world > 1:
-        dist.broadcast(eig, 0)
-    tp = train @ eig
-    cents = harness.train_codebooks(tp, bits, iters=15 if args.workload != "c5" else 8)
-    if world > 1:
-        for s in range(M):
-            t = torch.from_numpy(cents[s]).to(dev)
-            dist.broadcast(t, 0)
-            cents[s] = t.cpu().numpy()
-    del tp
-
-    v = vaq_amd.VaqHip(device=local_rank)
-    v.parseMethodString("VAQ%dm%dmin%dmax%dvar1,HEAP" % (sum(bits), M, min(bits), max(bits)))
-    v.mBitsAlloc = bits
-    v.mCentroidsPerSubs = cents
-    v.mEigenVectors = eig.cpu().numpy()
-    v.id_base = lo
-
-    codes = torch.empty((n_local, M), dtype=torch.int16, device=dev)
-    if real_codes:
-        c0, c1 = lo // GEN, (hi + GEN - 1) // GEN if hi > lo else lo // GEN
-        for c in range(c0, c1):
-            X = base_chunk(c)
-            a, b = max(lo, c * GEN), min(hi, (c + 1) * GEN)
-            xs = X[a - c * GEN: b - c * GEN]
-            # the product's own encoder (VAQ::encode on the GPU; projects with eig first)
-            codes[a - lo: b - lo] = v.encode_device(xs.contiguous(), projected=False)
-            del X, xs
-    else:
-        g = torch.Generator(device=dev).manual_seed(harness.SEED + rank)
-        step_rows = 1 << 24
-        for r in range(0, n_local, step_rows):
-            m = min(step_rows, n_local - r)
-            codes[r: r + m] = torch.randint(0, 256, (m, M), generator=g, device=dev, dtype=torch.int16)
-    ti_T = ti_seg = 0
+    ti = None
     if args.ti:
-        # VAQ::clusterTI: centres = k-means over decoded code rows (at most 256 per centre, as
-        # KMeans::staticFitCodebook samples, KMeans.hpp:618-650); training, so it runs in the harness
         parts = [int(x) for x in args.ti.split(",")]
-        ti_T, ti_seg = parts[0], (parts[1] if len(parts) > 1 else M)
-        g = torch.Generator(device="cpu").manual_seed(harness.SEED)
-        pick = torch.randperm(n_local, generator=g)[: min(n_local, 256 * ti_T)].to(dev)
-        samp = codes[pick].to(torch.int64) & 0xffff
-        L = D // M
-        dec = torch.cat([torch.from_numpy(cents[s]).to(dev)[samp[:, s]] for s in range(ti_seg)], dim=1)
-        cl = harness.kmeans(dec, ti_T, iters=25, seed=harness.SEED)
-        if world > 1:
-            dist.broadcast(cl, 0)
-        v.mTIClusters = cl.cpu().numpy()
-        v.mTISegmentNum = ti_seg
-        v.mTIClusterNum = ti_T
-        v.mMethods = vaq_amd.NNMethod.TI | vaq_amd.NNMethod.EA
-        v.mVisit = args.visit
-        del dec, samp, pick
-    if args.bucket_bits:
-        v._ensure_index()
-        v.set_option("bucket_bits", args.bucket_bits)
-    v.mCodebook = codes
-    v._ensure_codes()
-    host_codes = None
-    if rank == 0 and not args.no_cpu and world == 1:
-        n_cpu_rows = min(n_local, 1_000_000 if args.workload != "c5" else 4_000_000)
-        host_codes = codes[:n_cpu_rows].cpu().numpy().view(np.uint16)
-    del codes
-    v.mCodebook = None  # packed copy lives in the index; keep _codes_sig
-    torch.cuda.empty_cache()
+        ti = (parts[0], parts[1] if len(parts) > 1 else 0, args.visit)
+    small = wl in ("c2", "c3")
+    want_cpu = rank == 0 and not args.no_cpu and world == 1
+    v, host_codes, cents, (ti_T, ti_seg) = build_index(
+        bits, N, lo, hi, dev, local_rank, world, rank, iters=15 if small else 8,
+        random_codes=args.random_codes, ti=ti, bucket_bits=args.bucket_bits,
+        keep_host_rows=(1_000_000 if small else 4_000_000) if want_cpu else 0)
+    real_codes = not args.random_codes
 
-    # weak scaling: every rank draws its own query batch (disjoint generator streams)
-    queries = harness.sift_like(nq, D, stream=7 + (100 * rank if weak else 0), device=dev)
-    q_lo, q_hi = (0, nq) if (mode == "rows" or weak) else sharding.shard_bounds(nq, world, rank)
+    # replicas: every rank draws its own query batch (disjoint generator streams)
+    queries = harness.sift_like(nq, D, stream=7 + (100 * rank if replicas else 0), device=dev)
+    q_lo, q_hi = (0, nq) if (mode == "rows" or replicas) else sharding.shard_bounds(nq, world, rank)
     my_queries = queries[q_lo:q_hi].contiguous()
     nq_local = q_hi - q_lo
     if args.qb:
@@ -234,42 +389,42 @@ def main():
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the
     # labels and distances of a rank travel in ONE all-gather (packed [2, n, k] int32 buffer)
+    collective = world > 1 and not replicas
     per_q = (nq + world - 1) // world
-    n_pack = nq if (mode == "rows" or weak) else per_q
+    n_pack = nq if (mode == "rows" or replicas) else per_q
     pack_local, lab_view, dis_view = sharding.make_packed(n_pack, k, dev)
     out_local = (lab_view[:nq_local], dis_view[:nq_local])
     if nq_local < n_pack:  # short last query slice: the padding rows stay empty
         lab_view[nq_local:].fill_(-1)
         dis_view[nq_local:].fill_(3.4028234663852886e38)
-    gathered = torch.empty((world, 2, n_pack, k), dtype=torch.int32, device=dev) if (world > 1 and not weak) else None
+    gathered = torch.empty((world, 2, n_pack, k), dtype=torch.int32, device=dev) if collective else None
     out_final = (torch.empty((nq, k), dtype=torch.int32, device=dev),
-                 torch.empty((nq, k), dtype=torch.float32, device=dev)) if (world > 1 and not weak) else None
-    from vaq_amd.index import merge_topk_packed_device
+                 torch.empty((nq, k), dtype=torch.float32, device=dev)) if collective else None
+    # device time of the exchange step, per step: events on the stream everything is enqueued on
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)] if collective else None
 
-    def run_step():
+    def run_step(i=-1):
         l, d = v.search_device(my_queries, k, out=out_local)
-        if world > 1 and not weak:
+        if collective:
+            if i >= 0:
+                ev[i][0].record()
             sharding.all_gather_packed(pack_local, gathered)
+            if i >= 0:
+                ev[i][1].record()
             if mode == "rows":
                 l, d = merge_topk_packed_device(gathered, world, nq, k, out=out_final)
             else:  # disjoint query slices: the gathered planes ARE the result (strided views)
                 l = gathered[:, 0].reshape(world * per_q, k)[:nq]
                 d = gathered[:, 1].reshape(world * per_q, k)[:nq].view(torch.float32)
+            if i >= 0:
+                ev[i][2].record()
         return l, d
 
-    log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} info={info}")
+    log(f"[rank {rank}] setup {time.time() - t_setup:.1f}s rows_local={n_local} nq={nq} mode={mode} "
+        f"replicas={replicas} info={info}")
 
     # ---------------------------------------------------------------- timed --
-    # Settle (part of setup, untimed): the index build above frees several GB of
-    # staging memory, and the driver reclaims it asynchronously -- a one-off
-    # 40-60 ms stall of the GPU queue lands some milliseconds later
-    # (tools/step_times.py shows it in hipDeviceSynchronize, with normal kernel
-    # durations).  Run the step until 0.3 s have passed so it is not mistaken for
-    # a step time; the W warmup steps and K timed steps follow as the contract says.
-    t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.3:
-        run_step()
-        torch.cuda.synchronize()
+    settle(run_step)
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()
@@ -279,8 +434,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        labels, dists_ = run_step()
+    for i in range(args.steps):
+        labels, dists_ = run_step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -289,45 +444,70 @@ def main():
     tm = v.last_timing()  # mean per-kernel device time over exactly these K steps (HIP events
     #                       recorded on the launch stream by the library)
     v.set_option("timing", 0)
-    if world > 1:
+    exchange = None
+    if collective:
+        coll = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        mrg = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        stats = torch.tensor([elapsed, coll, mrg, tm["scan_ms"], float(n_local)], dtype=torch.float64, device=dev)
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)
+        allst = torch.stack(allst).cpu().numpy()
+        elapsed = float(allst[:, 0].max())
+        exchange = {
+            "world": world, "collective": "all_gather_into_tensor of one packed [2][nq][k] int32 buffer per rank "
+                                          "(%s)" % ("RCCL" if args.backend == "nccl" else args.backend),
+            "bytes_per_rank": int(2 * n_pack * k * 4),
+            "collective_ms": round(float(allst[:, 1].max()), 4), "merge_ms": round(float(allst[:, 2].max()), 4),
+            "scan_ms_per_rank": [round(float(x), 4) for x in allst[:, 3]],
+            "rows_local": [int(x) for x in allst[:, 4]],
+        }
+    elif world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    nq_total = nq * world if weak else nq
+    nq_total = nq * world if replicas else nq
     qps = nq_total * args.steps / elapsed
 
     # ------------------------------------------------------------- roofline --
-    # unit = one database row scanned in one pass; bytes = ceil(sum bits / 8);
-    # one launch scans n_local rows in `passes` = ceil(nq / Qb) passes.
-    # (per rank: this rank's rows x the passes its own queries need)
-    algo_bytes = float(n_local) * info["algo_code_bytes"] * tm["passes"]
-    achieved = algo_bytes / (tm["scan_ms"] * 1e-3) / 1e9 if tm["scan_ms"] > 0 else 0.0
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-        "kernel": "scan_%s%s_kernel" % ("bytes" if info["layout"] == 0 else "bits", "_ti" if args.ti else ""),
-        "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
-        "queries_per_pass": tm["queries_per_pass"], "passes": tm["passes"],
-        "algorithmic_bytes_per_launch": algo_bytes,
-        "effective_per_query_GBps": round(float(n_local) * info["algo_code_bytes"] * nq_local /
-                                          (tm["scan_ms"] * 1e-3) / 1e9, 1) if tm["scan_ms"] > 0 else 0.0,
+    # unit = one database row scanned in one pass; bytes = ceil(sum bits / 8).  That
+    # product is HBM traffic only when every row is read and nothing is shared through cache: a
+    # single pass over a database far beyond the 256 MB Infinity Cache with bucket skipping off.
+    # Whatever else this launch was, its kernel is described by `headline_kernel`; an HBM fraction
+    # is printed for it only in that streaming case.
+    kname = scan_kernel_name(info, tm, ti=bool(args.ti), no_skip=args.no_skip)
+    passes = tm["passes"]
+    eff = float(n_local) * info["algo_code_bytes"] * nq_local / (tm["scan_ms"] * 1e-3) / 1e9 if tm["scan_ms"] > 0 else 0.0
+    streaming = (args.no_skip and passes == 1 and tm["seed_slices"] == 0 and
+                 float(n_local) * info["algo_code_bytes"] > 1e9)
+    headline_kernel = {
+        "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
+        "queries_per_pass": tm["queries_per_pass"], "passes": passes,
         "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
                              "threshold_seed": round(tm["seed_ms"], 4), "merge": round(tm["merge_ms"], 4)},
         "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
+        "effective_per_query_GBps": round(eff, 1),
+        "effective_note": "rows x code bytes x queries / kernel time: counts rows pruned unread and rows "
+                          "served from L2 / Infinity Cache, so it is NOT an HBM rate and may exceed the peak",
     }
-
-    # HBM-side traffic of the scan kernel comes from separate rocprofv3 --pmc passes of this
-    # same command (tools/profile_gpu.sh); the corrected per-launch figure is committed under
-    # profiles/ and attached here when it matches the workload and plan.
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(args.workload)
-        if tr and world == 1 and not args.rows and not args.nq and not args.ti \
-                and tm["queries_per_pass"] == tr["queries_per_pass"]:
+    roofline = None
+    if streaming:
+        algo = float(n_local) * info["algo_code_bytes"] * passes
+        ach = algo / (tm["scan_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "workload": name + " (this run)",
+                    "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
+                    "algorithmic_bytes_per_launch": algo}
+        tr = load_profile_json("r02_traffic.json").get("c5_stream")
+        if tr and tr.get("rows") == n_local and tr.get("kernel") == kname:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
-    except (OSError, ValueError):
-        pass
+    else:
+        # counter-based description of a cache-resident, pruned scan (separate rocprofv3 --pmc passes
+        # of this same command: tools/profile_gpu.sh; the summary is committed under profiles/)
+        pm = load_profile_json("r02_bound.json").get(wl)
+        if pm and world == 1 and not args.rows and not args.nq and not args.ti and pm.get("kernel") == kname:
+            headline_kernel["bound"] = pm
 
     # --------------------------------------------------------------- recall --
     recall = None
@@ -335,7 +515,7 @@ def main():
         nq_r = min(nq, 1000)
         Xq = queries[:nq_r]
         nchunks = (N + GEN - 1) // GEN
-        gt = harness.brute_force_topk(Xq, ((c * GEN, base_chunk(c)) for c in range(nchunks)), k)
+        gt = harness.brute_force_topk(Xq, ((c * GEN, base_chunk(c, N, dev)) for c in range(nchunks)), k)
         recall = {
             "recall_at_100": round(harness.avg_recall(labels[:nq_r].cpu().numpy(), gt.cpu().numpy()), 4),
             "recall_1nn_in_100": round(harness.recall_at_r(labels[:nq_r].cpu().numpy(), gt.cpu().numpy()), 4),
@@ -344,9 +524,10 @@ def main():
 
     # --------------------------------------------------------- cpu baseline --
     cpu = None
+    parity = None
     # (rank 0 at N = 1 only: with several ranks on the box the host cores are shared with their
     #  runtime threads and the other ranks would sit in a barrier for the duration)
-    if rank == 0 and not args.no_cpu and world == 1:
+    if want_cpu:
         from oracle import pyoracle as po
         po.build(ref=False)
         threads = max(1, min(po.max_threads(), os.cpu_count() or 1))
@@ -387,7 +568,7 @@ def main():
                       + ("" if scale == 1.0 else f", scaled x{scale:.4g} to {N} rows"),
             "single_thread_qps": round(n1 / dt1 * scale, 2),
         }
-        if world == 1 and n_rows_cpu == n_local and args.ti:
+        if n_rows_cpu == n_local and args.ti:
             # distances must agree exactly; labels may differ only inside runs of equal distance
             chk = min(n_cpu, 32)
             gd = dists_[:chk].cpu().numpy()
@@ -396,38 +577,69 @@ def main():
             for q in range(chk):
                 for dv in np.unique(gd[q][:-1][gd[q][:-1] != gd[q][-1]]):
                     assert set(gl[q][gd[q] == dv]) == set(cl[q][cd[q] == dv]), "bench parity (TI): labels differ"
-            cpu["parity_checked_queries"] = chk
-        elif world == 1 and n_rows_cpu == n_local:
-            # same inputs: the CPU port is also the parity checker for the bench's own result
+            parity = {"checked_queries": chk, "contract": "TI: distances bit-exact, labels equal per run of equal distance"}
+        elif n_rows_cpu == n_local:
+            # same inputs: the CPU port is also the parity checker for the bench's own (timed) result
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from helpers import assert_topk_matches
-            chk = min(n_cpu, 32)
+            chk = min(n_cpu, args.parity_queries)
+            gl, gd = labels[:chk].cpu().numpy(), dists_[:chk].cpu().numpy()
             Xp = po.project(qh[:chk], eig_h)
-            ad = np.stack([po.all_dists(po.create_lut(Xp[q], cents, max(bits)), host_codes) for q in range(chk)])
-            assert_topk_matches(labels[:chk].cpu().numpy(), dists_[:chk].cpu().numpy(), cl[:chk], cd[:chk], ad,
-                                what="bench parity")
-            cpu["parity_checked_queries"] = chk
+            boundary = 0
+            interior = 0
+            for q in range(chk):
+                ad = po.all_dists(po.create_lut(Xp[q], cents, max(bits)), host_codes)[None]
+                boundary += assert_topk_matches(gl[q:q + 1], gd[q:q + 1], cl[q:q + 1], cd[q:q + 1], ad,
+                                                what="bench parity")
+                interior += int(np.any(np.diff(gd[q]) == 0))
+            parity = {
+                "checked_queries": chk, "distances_bit_exact": True,
+                "boundary_tie_queries": boundary,
+                "queries_with_equal_distances_inside_topk": interior,
+                "contract": "distances bit-exact rank for rank; labels equal after sorting each run of equal "
+                            "distances; a boundary tie (k-th == (k+1)-th distance) keeps the smallest labels "
+                            "where the reference's choice depends on its heap (DESIGN.md 'Ties')",
+            }
+        cpu["parity_checked_queries"] = parity["checked_queries"] if parity else 0
+    v.close()
+    del v
+    torch.cuda.empty_cache()
+
+    # ----------------------------------------- N = 1 default: the HBM leg --
+    scale_base = None
+    if world == 1 and args.workload == "auto" and not args.no_c5_leg and not args.ti:
+        roofline, scale_base = c5_leg(args, dev, local_rank, k)
+    if roofline is None:
+        roofline = {"bound": "lds+issue (cache-resident, bucket-pruned scan: no HBM roofline applies)",
+                    "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4)}
 
     if rank == 0:
         out = {
             "metric": "queries/sec (ADC search, recall@100 reported alongside)",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak" if replicas else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": name, "rows": N, "rows_per_gpu": shard, "queries_per_step": nq_total,
-                       "queries_per_gpu": nq if (weak or world == 1) else (nq if mode == "rows" else per_q), "k": k,
+            "config": {"workload": name, "rows": N, "rows_per_gpu": n_local if mode != "rows" else (N + world - 1) // world,
+                       "queries_per_step": nq_total,
+                       "queries_per_gpu": nq if (replicas or world == 1 or mode == "rows") else per_q, "k": k,
                        "bits": bits, "code_bytes": info["algo_code_bytes"],
                        "codes": "encoded" if real_codes else "uniform-random",
                        "method": ("EA_TI%dm%d visit=%g (k-means centres over decoded codes)" % (ti_T, ti_seg, args.visit))
                        if args.ti else "HEAP/EA (exhaustive)",
                        "sharding": "none" if world == 1 else (
-                           "weak: index replicated on every GPU, each GPU answers its own batch of queries, "
-                           "results stay with their owner (no data-path collective)" if weak else
+                           "replicas: index replicated on every GPU, each GPU answers its own batch of queries, "
+                           "results stay with their owner (no data-path collective)" if replicas else
                            "rows: contiguous shards, RCCL all-gather of per-shard top-k + merge" if mode == "rows"
                            else "queries: codes replicated (fit HBM), disjoint query slices, RCCL all-gather of results")},
-            "roofline": roofline, "cpu_baseline": cpu, "recall": recall,
+            "roofline": roofline, "headline_kernel": headline_kernel, "cpu_baseline": cpu, "recall": recall,
+            "parity": parity,
         }
+        if exchange:
+            out["exchange"] = exchange
+        if scale_base:
+            out["scale_base"] = scale_base
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

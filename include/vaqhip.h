@@ -266,6 +266,7 @@ typedef struct {
   int passes;                                  /* ceil(nq / Qb)                 */
   int lds_bytes;                               /* LDS per scan workgroup        */
   int seed_slices;                             /* row slices of the pre-pass (0 = none) */
+  int early_abandon;                           /* form the scan ran in: 0 none, 1 queue, 2 in place */
 } vaqhip_timing;
 int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
 

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(vaqlib):
 
 
 def test_version_and_error_string(vaqlib):
-    assert vaqlib.vaqhip_version() == 100
+    assert vaqlib.vaqhip_version() >= 100
     assert isinstance(vaqlib.vaqhip_last_error(), bytes)
 
 
@@ -80,3 +80,42 @@ def test_parse_method_string():
         v.parseMethodString("VAQ128m32min6max9var0.95,SORT")
     with pytest.raises(vaq_amd.VaqHipError):
         v.parseMethodString("VAQ128m32min2max4var1,FAST")
+
+
+def test_bench_plan_defaults():
+    """What `bench.py --gpus N` runs by default: one GPU = c2 (the metric's configuration);
+    several GPUs = the north-star path (c5, strong scaling, row shards + all-gather + merge);
+    replicas only by name."""
+    from vaq_amd import sharding
+    p1 = sharding.bench_plan(1)
+    assert (p1["workload"], p1["rows"], p1["nq"], p1["scaling"], p1["replicas"]) == ("c2", 1_000_000, 10_000, "strong", False)
+    for w in (2, 4, 8):
+        p = sharding.bench_plan(w)
+        assert (p["workload"], p["rows"], p["nq"]) == ("c5", 1_000_000_000, 10_000)
+        assert p["mode"] == "rows" and p["scaling"] == "strong" and not p["replicas"]
+        assert p["bits"] == [8] * 16
+        lo, hi = sharding.shard_bounds(p["rows"], w, w - 1)
+        assert hi == p["rows"] and hi - lo == p["rows"] // w
+    p = sharding.bench_plan(8, "c2")
+    assert p["mode"] == "rows" and p["scaling"] == "strong"
+    p = sharding.bench_plan(8, "c2", "replicas")
+    assert p["replicas"] and p["scaling"] == "weak" and p["mode"] == "queries"
+    assert sharding.bench_plan(8, "c2", "weak")["replicas"]
+    p = sharding.bench_plan(4, "c4", "auto", "queries", rows=1000, nq=64)
+    assert (p["mode"], p["rows"], p["nq"]) == ("queries", 1000, 64)
+    assert not sharding.bench_plan(1, "c2", "replicas")["replicas"]  # one GPU has nothing to replicate
+
+
+def test_member_identity_tokens():
+    """index.py re-uploads a member when it is REPLACED; the token is a weak reference, so an
+    array allocated at a recycled id() is never mistaken for the one that was uploaded."""
+    from vaq_amd.index import _same, _wref
+    a = np.zeros((4, 2), np.float32)
+    r = _wref(a)
+    assert _same(r, a) and not _same(r, a.copy()) and not _same(r, None)
+    assert _same(None, None) and not _same(None, a)
+    del a
+    b = np.zeros((4, 2), np.float32)  # may reuse the freed id
+    assert not _same(r, b)
+    lst = [1, 2, 3]
+    assert _same(_wref(lst), lst)

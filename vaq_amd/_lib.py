@@ -49,7 +49,7 @@ class Timing(C.Structure):
                 ("scan_ms", C.c_float),
                 ("merge_ms", C.c_float), ("n_searches", C.c_int), ("queries_per_pass", C.c_int), ("slices", C.c_int),
                 ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int),
-                ("seed_slices", C.c_int)]
+                ("seed_slices", C.c_int), ("early_abandon", C.c_int)]
 
 
 _lib = None

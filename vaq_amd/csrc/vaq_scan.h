@@ -815,7 +815,10 @@ template <int M> struct BytesItem {
 //       reference's order, abandoning after each, and admit to the k-min.
 // Results are identical to EA = false, which sums every row completely.
 // ---------------------------------------------------------------------------
-template <int M, int QB, int EA, bool TI>
+// STREAM = true: the measurement form of the in-place kernel (`bucket_skip` = 0): every bucket is
+// visited, so one launch streams the whole code array once; a separate instantiation so that
+// profilers list it under its own name
+template <int M, int QB, int EA, bool TI, bool STREAM = false>
 __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
   typedef typename LutVec<QB>::T LT;
   typedef BytesItem<M> Item;
@@ -1066,7 +1069,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
             }
           }
           STAT_ADD(ST_BUCKETS_TESTED, 1);
-          if (TI || p.no_skip || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
+          if (TI || STREAM || p.no_skip || cx.survives(lbq)) {  // otherwise no row of the bucket can be admitted: skip its codes
             STAT_ADD(ST_BUCKETS_VISITED, 1);
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment

@@ -8,9 +8,9 @@ template <int M, int QB, int EA>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_kernel(ScanParams p) {
   scan_bytes_body<M, QB, EA, false>(p);
 }
-template <int M, int QB>
+template <int M, int QB, bool STREAM>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) void scan_bytes_inplace_kernel(ScanParams p) {
-  scan_bytes_body<M, QB, EA_INPLACE, false>(p);
+  scan_bytes_body<M, QB, EA_INPLACE, false, STREAM>(p);
 }
 // triangle-inequality form (VAQ::searchTriangleInequality): one query per workgroup,
 // survivors queued; the bit-packed one always allows spilled tables
@@ -23,7 +23,9 @@ __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_ti
   switch (p.ea) {                                                                         \
   case EA_NONE: return launch_scan_kernel(scan_bytes_kernel<A, Q, EA_NONE>, p, lds, grid, st);   \
   case EA_QUEUE: return launch_scan_kernel(scan_bytes_kernel<A, Q, EA_QUEUE>, p, lds, grid, st); \
-  case EA_INPLACE: return launch_scan_kernel(scan_bytes_inplace_kernel<A, Q>, p, lds, grid, st); \
+  case EA_INPLACE:                                                                        \
+    return p.no_skip ? launch_scan_kernel(scan_bytes_inplace_kernel<A, Q, true>, p, lds, grid, st) \
+                     : launch_scan_kernel(scan_bytes_inplace_kernel<A, Q, false>, p, lds, grid, st); \
   default: return hipErrorInvalidValue;                                                   \
   }
 #define VAQ_DISPATCH_QB(A)                                                                \

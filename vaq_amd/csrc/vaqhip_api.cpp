@@ -455,6 +455,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                                   ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
       if (timing) HIP_TRY(hipEventRecord(ev[5], st));
       tm.seed_slices = 0;
+      tm.early_abandon = pl.ea;
       tm.queries_per_pass = 1;
       tm.slices = pl.n_slices;
       tm.workgroups = grid;
@@ -524,6 +525,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                                 nullptr, ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
     if (timing) HIP_TRY(hipEventRecord(ev[5], st));
     tm.seed_slices = pl.seed_slices;
+    tm.early_abandon = pl.ea;
     tm.queries_per_pass = pl.qb;
     tm.slices = pl.n_slices;
     tm.workgroups = grid;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import re
+import weakref
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -39,6 +40,23 @@ class LabelDistVec:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _wref(obj):
+    """Identity token of a member that was uploaded: a weak reference (an id() can be recycled
+    by a new array once the old one is freed; a dead weak reference never compares alive)."""
+    if obj is None:
+        return None
+    try:
+        return weakref.ref(obj)
+    except TypeError:  # plain lists / tuples: fall back to the object itself (small)
+        return lambda o=obj: o
+
+
+def _same(ref, obj) -> bool:
+    if ref is None or obj is None:
+        return ref is None and obj is None
+    return ref() is obj
 
 
 class VaqHip:
@@ -173,10 +191,12 @@ class VaqHip:
             eig = np.ascontiguousarray(np.real(self.mEigenVectors), dtype=np.float32)
             if eig.shape != (D, D):
                 raise _lib.VaqHipError(-1, f"mEigenVectors {eig.shape} is not {D}x{D}")
-        sig = (tuple(self.mBitsAlloc), tuple(id(c) for c in self.mCentroidsPerSubs),
-               id(self.mEigenVectors), self.device, self.sequential_sum)
-        if self._h and sig == self._sig:
+        plain = (tuple(self.mBitsAlloc), self.device, self.sequential_sum)
+        if (self._h and self._sig is not None and self._sig[0] == plain
+                and len(self._sig[1]) == M and all(_same(r, c) for r, c in zip(self._sig[1], self.mCentroidsPerSubs))
+                and _same(self._sig[2], self.mEigenVectors)):
             return
+        sig = (plain, tuple(_wref(c) for c in self.mCentroidsPerSubs), _wref(self.mEigenVectors))
         self.close()
         bits = (C.c_int * M)(*self.mBitsAlloc)
         arr = (C.POINTER(C.c_float) * M)()
@@ -237,10 +257,9 @@ class VaqHip:
             seg = self.mTISegmentNum if self.mTISegmentNum != -1 else self.mHighestSubs
             if cl.ndim != 2 or cl.shape[1] != seg * self.mSubsLen:
                 raise _lib.VaqHipError(-1, f"mTIClusters {cl.shape} is not T x {seg * self.mSubsLen}")
-            sig = (id(self.mTIClusters), seg)
-            if sig != self._ti_sig:
+            if self._ti_sig is None or self._ti_sig[1] != seg or not _same(self._ti_sig[0], self.mTIClusters):
                 _lib.check(L.vaqhip_index_set_ti_clusters(self._h, _ptr(cl), cl.shape[0], seg))
-                self._ti_sig = sig
+                self._ti_sig = (_wref(self.mTIClusters), seg)
         elif self._ti_sig is not None:
             _lib.check(L.vaqhip_index_set_ti_clusters(self._h, None, 0, 0))
             self._ti_sig = None
@@ -256,13 +275,17 @@ class VaqHip:
             if self._codes_sig is not None:
                 return  # the packed copy already lives on the device (host copy was dropped)
             raise _lib.VaqHipError(-7, "mCodebook is not set")
-        sig = (id(self.mCodebook), self.id_base)
-        if sig == self._codes_sig:
+        if (self._codes_sig is not None and self._codes_sig[1] == self.id_base
+                and _same(self._codes_sig[0], self.mCodebook)):
             return
+        sig = (_wref(self.mCodebook), self.id_base)
         cb = self.mCodebook
         if hasattr(cb, "data_ptr"):  # torch tensor already on the device: N x M int16/uint16
             if cb.dim() != 2 or cb.shape[1] != len(self.mBitsAlloc) or cb.element_size() != 2:
                 raise _lib.VaqHipError(-1, "device mCodebook must be N x M 16-bit")
+            if not cb.is_cuda or cb.device.index != self.device or not cb.is_contiguous():
+                raise _lib.VaqHipError(-1, f"device mCodebook must be a contiguous tensor on cuda:{self.device} "
+                                           f"(got {cb.device}, contiguous={cb.is_contiguous()})")
             import torch
             st = torch.cuda.current_stream(cb.device).cuda_stream
             _lib.check(_lib.load().vaqhip_index_set_codes_u16_device(
@@ -286,7 +309,7 @@ class VaqHip:
         _lib.check(_lib.load().vaqhip_index_add_codes_u16(self._h, _ptr(cb), cb.shape[0]))
         if self.mCodebook is not None and not hasattr(self.mCodebook, "data_ptr"):
             self.mCodebook = np.concatenate([np.asarray(self.mCodebook, dtype=np.uint16), cb])
-            self._codes_sig = (id(self.mCodebook), self.id_base)
+            self._codes_sig = (_wref(self.mCodebook), self.id_base)
 
     # ------------------------------------------------------------- search --
     def search(self, XTest: np.ndarray, k: int, verbose: bool = False,
@@ -388,6 +411,14 @@ class VaqHip:
         out = np.empty_like(X)
         _lib.check(_lib.load().vaqhip_project(self._h, _ptr(X), X.shape[0], _ptr(out)))
         return out
+
+    def invalidate(self) -> None:
+        """Members are re-uploaded when they are REPLACED (a different object); after editing
+        mCodebook, the centroid matrices, mEigenVectors or mTIClusters IN PLACE call this so
+        that the next search rebuilds the device index from the current contents."""
+        self.close()
+        self._ti_sig = None
+        self._method_sig = None
 
     def set_option(self, key: str, value: int) -> None:
         self._ensure_index()

@@ -34,6 +34,40 @@ def choose_mode(n_rows: int, code_bytes: int, nq: int, world: int, requested: st
     return "queries" if (fits and enough) else "rows"
 
 
+# BASELINE.json configs the bench knows (bits per subspace, rows, queries per step)
+BENCH_WORKLOADS = {
+    "c2": dict(bits=[8] * 8, rows=1_000_000, nq=10_000, name="sift1m-shaped d128 m8x256 nq10k k100"),
+    "c3": dict(bits=[12, 10, 9, 8, 8, 7, 6, 4], rows=1_000_000, nq=10_000,
+               name="sift1m-shaped d128 bits{12,10,9,8,8,7,6,4} nq10k k100"),
+    "c4": dict(bits=[8] * 8, rows=100_000_000, nq=10_000, name="synthetic 100Mx128 m8x256 nq10k k100"),
+    "c5": dict(bits=[8] * 16, rows=1_000_000_000, nq=10_000, name="synthetic 1Bx128 m16x256 nq10k k100"),
+}
+
+
+def bench_plan(world: int, workload: str = "auto", scaling: str = "auto", shard: str = "auto",
+               rows: int = 0, nq: int = 0) -> dict:
+    """What `bench.py --gpus <world>` runs.  Defaults: one GPU -> c2 (the configuration the metric
+    is quoted on); several GPUs -> the north-star path: c5, strong scaling, contiguous row
+    shards + one RCCL all-gather + merge.  Replicas (every GPU its own queries on a replicated
+    index, no collective) only when asked for by name."""
+    if workload == "auto":
+        workload = "c2" if world == 1 else "c5"
+    w = dict(BENCH_WORKLOADS[workload])
+    if rows:
+        w["rows"] = rows
+    if nq:
+        w["nq"] = nq
+    replicas = world > 1 and scaling in ("replicas", "weak")
+    if replicas:
+        mode = "queries"  # the whole index on every rank
+    elif shard in ("rows", "queries"):
+        mode = shard
+    else:
+        mode = "rows"
+    return dict(workload=workload, rows=w["rows"], nq=w["nq"], bits=w["bits"], name=w["name"],
+                replicas=replicas, mode=mode, scaling="weak" if replicas else "strong")
+
+
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous row range [lo, hi) of `rank`: ceil(N/world) rows per shard,
     the last shards may be short or empty."""
