@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--order", type=int, default=0, help="best-first slice order on/off (experimental)")
     ap.add_argument("--seed-frac", type=int, default=0, help="pre-pass scans N / this many rows (0 = default 64)")
     ap.add_argument("--hot", type=int, default=-1, help="best-first buckets per workgroup (0..32, -1 = default)")
+    ap.add_argument("--bf", type=int, default=-1, help="best-first scan form on/off (-1 = library default)")
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
                                              "seg subspaces (default all), method EA_TI (not the headline metric)")
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
@@ -203,6 +204,8 @@ def scan_kernel_name(info, tm, ti=False, no_skip=False):
         if tm["early_abandon"] == 2:
             return "scan_bytes_inplace_kernel<%d, %d, %s>" % (info["M"], tm["queries_per_pass"],
                                                               "true" if no_skip else "false")
+        if tm.get("best_first"):
+            return "scan_bytes_bf_kernel<%d, %s>" % (info["M"], "true" if info.get("bucket_shift", 0) == 0 else "false")
         return "scan_bytes_kernel<%d, %d, %d>" % (info["M"], tm["queries_per_pass"], tm["early_abandon"])
     return "scan_bits_kernel (W=%d, Qb=%d, ea=%d)" % ((info["total_bits"] + 31) // 32, tm["queries_per_pass"],
                                                        tm["early_abandon"])
@@ -385,6 +388,8 @@ def main():
         v.set_option("hot_buckets", args.hot)
     if args.no_skip:
         v.set_option("bucket_skip", 0)
+    if args.bf >= 0:
+        v.set_option("best_first", args.bf)
     info = v.info()
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the

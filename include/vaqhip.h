@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VAQHIP_VERSION 100
+#define VAQHIP_VERSION 101
 
 /* error codes */
 #define VAQHIP_OK            0
@@ -247,7 +247,12 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       0 never (VAQ::searchHeap as written), 1 survivors are
  *                       compacted through an LDS queue, 2 survivors finish in
  *                       place, 3 (default) 1 or 2 chosen per search            */
-/*   "bucket_bits"       0 (default) = auto, else 1..12: width of the key the rows are bucketed by
+/*   "best_first"        1 (default): a one-query workgroup whose row slice spans many buckets (the
+ *                       cache-resident databases) visits ALL of them in ascending order of their
+ *                       bound, work units handed to its waves by ticket, and stops at the first
+ *                       bucket out of reach ("best-first form"); 0: the
+ *                       16-hot-buckets-then-natural-order form.  Results are identical.
+ *   "bucket_bits"       0 (default) = auto, else 1..12: width of the key the rows are bucketed by
  *                       (top bits of the first code, continued into the second); takes
  *                       effect when the codes are (re)set
  *   "bucket_skip"       1 (default); 0 visits every bucket -- for measuring the streaming
@@ -267,6 +272,7 @@ typedef struct {
   int lds_bytes;                               /* LDS per scan workgroup        */
   int seed_slices;                             /* row slices of the pre-pass (0 = none) */
   int early_abandon;                           /* form the scan ran in: 0 none, 1 queue, 2 in place */
+  int best_first;                              /* 1: the best-first form ("best_first" option) ran */
 } vaqhip_timing;
 int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
 

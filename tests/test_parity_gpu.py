@@ -56,13 +56,15 @@ def test_golden(vaqlib, oracle, name):
         if not key.startswith("labels_k"):
             continue
         k = int(key[len("labels_k"):])
-        for qb, ea in [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0), (1, 2), (2, 2), (4, 2), (2, 3)]:
+        for qb, ea, bf in [(1, 1, 1), (1, 1, 0), (2, 1, 1), (4, 1, 1), (1, 0, 1), (2, 0, 1), (4, 0, 1), (1, 2, 1),
+                           (2, 2, 1), (4, 2, 1), (2, 3, 1)]:
             v.set_option("queries_per_pass", qb)
             v.set_option("early_abandon", ea)
+            v.set_option("best_first", bf)
             ans = v.search(z["X"], k)
             nq = z["X"].shape[0]
             assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k),
-                                z[key], z[f"dists_k{k}"], ad, what=f"{name} k={k} qb={qb} ea={ea}")
+                                z[key], z[f"dists_k{k}"], ad, what=f"{name} k={k} qb={qb} ea={ea} bf={bf}")
 
 
 CONFIGS = [
@@ -98,16 +100,25 @@ def test_search_matches_oracle(vaqlib, oracle, cfg):
     o_lut = np.stack([oracle.create_lut(Xp[q], c["cents"], max(bits)) for q in range(nq)])
     assert np.array_equal(lut.view(np.uint32), o_lut.view(np.uint32))
     ties = 0
-    for qb, slices, ea, hot in [(1, 0, 1, 16), (2, 0, 1, 16), (4, 0, 1, 32), (2, 1, 1, 0), (2, 3, 1, 5),
-                                (1, 7, 1, 16), (2, 0, 0, 16), (4, 3, 0, 0), (1, 1, 0, 16), (2, 0, 2, 16),
-                                (1, 5, 2, 32), (4, 1, 2, 1), (1, 1, 1, 32), (1, 1, 2, 0)]:
+    bf_ran = 0
+    for qb, slices, ea, hot, bf in [(1, 0, 1, 16, 1), (1, 0, 1, 16, 0), (2, 0, 1, 16, 1), (4, 0, 1, 32, 1),
+                                    (2, 1, 1, 0, 1), (2, 3, 1, 5, 1), (1, 7, 1, 16, 0), (1, 7, 1, 16, 1),
+                                    (1, 2, 1, 16, 1), (2, 0, 0, 16, 1), (4, 3, 0, 0, 1), (1, 1, 0, 16, 1),
+                                    (2, 0, 2, 16, 1), (1, 5, 2, 32, 1), (4, 1, 2, 1, 1), (1, 1, 1, 32, 0),
+                                    (1, 1, 1, 32, 1), (1, 1, 2, 0, 1)]:
         v.set_option("queries_per_pass", qb)
         v.set_option("slices", slices)
         v.set_option("early_abandon", ea)
         v.set_option("hot_buckets", hot)
+        v.set_option("best_first", bf)
+        v.set_option("timing", 1)
         ans = v.search(c["X"], k)
+        bf_ran += v.last_timing()["best_first"]
+        v.set_option("timing", 0)
         ties += assert_topk_matches(ans.labels.reshape(nq, k), ans.distances.reshape(nq, k), o_lab, o_dis,
-                                    ad, what=f"cfg{seed} qb={qb} slices={slices} ea={ea} hot={hot}")
+                                    ad, what=f"cfg{seed} qb={qb} slices={slices} ea={ea} hot={hot} bf={bf}")
+    if all(b == 8 for b in bits) and len(bits) in (8, 16, 32) and N >= 5000:
+        assert bf_ran >= 3, bf_ran  # the best-first form has kernels for the byte layout
     if kw.get("integer"):
         assert ties > 0  # the boundary-tie rule was exercised
 

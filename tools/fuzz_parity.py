@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 po.build(ref=False)
-t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0; n_ti = 0; t_print = t0
+t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0; n_ti = 0; n_bf = 0; t_print = t0
 
 
 def visited_dists(c, ti, T, seg, visit, k, Xp):
@@ -41,11 +41,12 @@ def visited_dists(c, ti, T, seg, visit, k, Xp):
 while time.time() - t0 < budget:
     if time.time() - t_print > 20:
         t_print = time.time()
-        print(f"[{t_print - t0:.0f}s] {n_cases} indexes, {n_searches} searches ({n_ti} TI)", flush=True)
-    M = int(rng.choice([4, 8, 8, 12, 16, 16, 20, 32, 64]))
+        print(f"[{t_print - t0:.0f}s] {n_cases} indexes, {n_searches} searches ({n_ti} TI, {n_bf} best-first)", flush=True)
+    M = int(rng.choice([4, 8, 8, 8, 12, 16, 16, 20, 32, 64]))
     L = int(rng.choice([1, 2, 4, 8, 16]))
     D = M * L
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)  # (two of five: every code 8 bits -- the byte layout and its best-first form)
+    kind = 0 if kind == 4 else kind
     if kind == 0:
         bits = [8] * M
     elif kind == 1:
@@ -73,11 +74,13 @@ while time.time() - t0 < budget:
         opts = dict(queries_per_pass=int(rng.choice([0, 1, 2, 4])), early_abandon=int(rng.integers(0, 4)),
                     slices=int(rng.choice([0, 0, 1, 2, 5, 300])), hot_buckets=int(rng.choice([0, 3, 16, 32])),
                     waves_per_workgroup=int(rng.choice([0, 4, 8, 16])), seed_thresholds=int(rng.integers(0, 2)),
-                    ordered_slices=int(rng.integers(0, 2)))
+                    ordered_slices=int(rng.integers(0, 2)), best_first=int(rng.integers(0, 3) > 0))
         for key, val in opts.items():
             v.set_option(key, val)
+        v.set_option("timing", 1)
         try:
             a = v.search(c["X"], k)
+            n_bf += v.last_timing()["best_first"]
         except vaq_amd.VaqHipError as e:
             if e.code == -2:  # outside this build's limits (reported, not a parity failure)
                 n_unsupported = globals().get("n_unsupported", 0) + 1
@@ -126,4 +129,5 @@ while time.time() - t0 < budget:
                 n_searches += 1; n_ti += 1
     v.close(); n_cases += 1
 print("unsupported (EUNSUPPORTED) cases:", globals().get("n_unsupported", 0))
-print(f"fuzz ok: {n_cases} indexes, {n_searches} searches, {ties} boundary-tie queries, {time.time()-t0:.0f}s, seed {seed}")
+print(f"fuzz ok: {n_cases} indexes, {n_searches} searches ({n_bf} in the best-first form), {ties} boundary-tie queries, "
+      f"{time.time()-t0:.0f}s, seed {seed}")

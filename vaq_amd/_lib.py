@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libvaqhip.so")
+_LIB_PATH = os.environ.get("VAQHIP_LIB") or os.path.join(_HERE, "lib", "libvaqhip.so")
 
 # every symbol include/vaqhip.h declares
 SYMBOLS = [
@@ -49,7 +49,8 @@ class Timing(C.Structure):
                 ("scan_ms", C.c_float),
                 ("merge_ms", C.c_float), ("n_searches", C.c_int), ("queries_per_pass", C.c_int), ("slices", C.c_int),
                 ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int),
-                ("seed_slices", C.c_int), ("early_abandon", C.c_int)]
+                ("seed_slices", C.c_int), ("early_abandon", C.c_int),
+                ("best_first", C.c_int)]
 
 
 _lib = None

@@ -13,12 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vaq_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "vaq_amd", "lib")
 LIB = os.path.join(LIBDIR, "libvaqhip.so")
-SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
+SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
 KERNEL_HEADER = os.path.join(CSRC, "vaq_kernels.h")
 API_HEADER = os.path.join(ROOT, "include", "vaqhip.h")
 
 
 SCAN_HEADER = os.path.join(CSRC, "vaq_scan.h")
+SCAN_BF_HEADER = os.path.join(CSRC, "vaq_scan_bf.h")
 
 
 def _deps(src: str):
@@ -26,10 +27,23 @@ def _deps(src: str):
     deps = [os.path.join(CSRC, src), KERNEL_HEADER]
     if src.endswith(".cpp"):
         deps.append(API_HEADER)
-    if src in ("vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip"):
+    if src in ("vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip"):
         deps.append(SCAN_HEADER)
+    if src in ("vaq_kernels.hip", "vaq_scan_bf.hip"):
+        deps.append(SCAN_BF_HEADER)
     return deps
 OBJDIR = os.path.join(LIBDIR, "obj")
+# Experiment builds: VAQ_VARIANT=name compiles (with VAQ_EXTRA_FLAGS) into vaq_amd/lib/variants/name/
+# and VAQHIP_LIB=<path> makes the package load that library instead (tools/ sweeps).
+_VARIANT = os.environ.get("VAQ_VARIANT", "")
+# VAQ_VARIANT_ONLY="a.hip b.hip": only these units are compiled with the variant's flags, the
+# others are linked from the main build's objects (which must be up to date)
+_VARIANT_ONLY = os.environ.get("VAQ_VARIANT_ONLY", "").split()
+_MAIN_OBJDIR = OBJDIR
+if _VARIANT:
+    LIBDIR = os.path.join(LIBDIR, "variants", _VARIANT)
+    LIB = os.path.join(LIBDIR, "libvaqhip.so")
+    OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def _flags_tag() -> str:
@@ -37,7 +51,10 @@ def _flags_tag() -> str:
 
 
 def _obj(src: str) -> str:
-    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    d = OBJDIR
+    if _VARIANT and _VARIANT_ONLY and src not in _VARIANT_ONLY:
+        d = _MAIN_OBJDIR
+    return os.path.join(d, os.path.splitext(src)[0] + ".o")
 
 
 def _obj_stale(src: str) -> bool:
@@ -54,13 +71,16 @@ def _obj_stale(src: str) -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """Compile each translation unit to an object (in parallel, only the stale
     ones) and link them into libvaqhip.so."""
+    if os.environ.get("VAQHIP_LIB") and not _VARIANT:
+        return os.environ["VAQHIP_LIB"]  # a prebuilt experiment library was named: leave it alone
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
               "-ffp-contract=off", "-fno-fast-math", "-Wall",
               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     extra = _flags_tag().split()
-    todo = [s for s in SOURCES if force or _obj_stale(s)]
+    todo = [s for s in SOURCES if (force or _obj_stale(s)) and
+            not (_VARIANT and _VARIANT_ONLY and s not in _VARIANT_ONLY)]
     procs = []
     for s in todo:
         cmd = common + extra + ["-c", os.path.join(CSRC, s), "-o", _obj(s)]

@@ -13,6 +13,7 @@
 //                       vaq_scan_bytes.hip and vaq_scan_bits.hip
 //   merge_kernel        heap_reorder's sorted output         utils/Heap.hpp:322-349
 #include "vaq_scan.h"
+#include "vaq_scan_bf.h"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -491,6 +492,7 @@ hipError_t launch_scan(const ScanParams &p_in, int *grid_out, hipStream_t st) {
   const int grid = ((total + 7) / 8) * 8;
   if (grid_out) *grid_out = grid;
   if (total == 0) return hipSuccess;
+  if (p.bf) return launch_scan_bf(p, grid, st);
   size_t lds = scan_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.qb, p.k, p.ea, p.nwaves, p.n_buckets,
                               p.bucket_shift, p.bucket_t);
   if (p.bucket_t < 0 || p.bucket_t > GMIN_MAX_BITS || (p.bucket_t > 0 && p.bucket_shift != 0))

@@ -91,7 +91,7 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -124,6 +124,7 @@ struct Plan {
   int seed_slices;
   int64_t seed_rows, seed_stride;
   bool ordered;  // slices dispatched best-first per query batch
+  bool bf = false;  // best-first scan form (vaq_scan_bf.h)
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -232,6 +233,31 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       pl->seed_slices = (int)ss;
       pl->seed_rows = srows;
       pl->seed_stride = stride;
+    }
+  }
+  // Best-first form: when a workgroup's slice spans many buckets (the cache-resident databases), all
+  // of them are visited in ascending order of their bound with work units handed out by ticket.
+  pl->bf = false;
+  if (ix->opt_bf && ea == vaq::EA_QUEUE && qb == 1 && !pl->ordered && subs == ix->M &&
+      vaq::scan_bf_supported(ix->layout, ix->M, qb, ea, ix->n_buckets, ix->seq) && ix->n_buckets >= 16 &&
+      pl->slice_rows >= 8 * (N / ix->n_buckets + 1)) {
+    int bnw = 0, bscore = 0;
+    size_t blds = 0;
+    for (int nw : {4, 8, 16}) {
+      if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
+      const size_t lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, k, nw, ix->n_buckets);
+      if (lds > LDS_LIMIT) continue;
+      const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
+      // small workgroups win here even at lower residency: setup, bootstrap and the final sort
+      // are per workgroup and leave its other waves idle (C2: 4 waves x 6 workgroups per CU
+      // 1.02 ms, 8 x 4 1.15 ms, 16 x 2 1.8 ms)
+      const int score = nw == 4 ? wgs * nw * 10 : nw == 8 ? wgs * nw * 7 : wgs * nw * 4;
+      if (score > bscore) { bscore = score; bnw = nw; blds = lds; }
+    }
+    if (bnw) {
+      pl->bf = true;
+      pl->nwaves = bnw;
+      pl->lds = blds;
     }
   }
   return VAQHIP_OK;
@@ -379,6 +405,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bucket_shift = ix->bucket_shift;
     sp.bucket_t = ix->bucket_t;
     sp.n_hot = 0;
+    sp.bf = 0;
     sp.no_skip = ix->opt_no_skip;
     sp.stats = nullptr;
 #ifdef VAQ_STATS
@@ -499,6 +526,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.n_hot = (ix->opt_hot && sp.n_buckets >= 16 && sp.n_buckets <= 4096 &&
                 (int64_t)sp.n_buckets <= (int64_t)(ix->layout == vaq::LAYOUT_BYTES ? ix->M * 256 : pl.lut_lds_entries) * pl.qb &&
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
+    sp.bf = pl.bf ? 1 : 0;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
 #ifdef VAQ_STATS
     {
@@ -526,6 +554,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     if (timing) HIP_TRY(hipEventRecord(ev[5], st));
     tm.seed_slices = pl.seed_slices;
     tm.early_abandon = pl.ea;
+    tm.best_first = pl.bf ? 1 : 0;
     tm.queries_per_pass = pl.qb;
     tm.slices = pl.n_slices;
     tm.workgroups = grid;
@@ -1175,6 +1204,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "bucket_bits") {
     if (value < 0 || value > 12) return fail(VAQHIP_EINVAL, "bucket_bits must be 0..12");
     ix->opt_bucket_bits = (int)value;  // takes effect when the codes are (re)set
+  } else if (k == "best_first") {
+    ix->opt_bf = value != 0;
   } else if (k == "seed_thresholds") {
     ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
