@@ -207,6 +207,8 @@ def scan_kernel_name(info, tm, ti=False, no_skip=False):
         if tm.get("best_first"):
             return "scan_bytes_bf_kernel<%d, %s>" % (info["M"], "true" if info.get("bucket_shift", 0) == 0 else "false")
         return "scan_bytes_kernel<%d, %d, %d>" % (info["M"], tm["queries_per_pass"], tm["early_abandon"])
+    if tm.get("best_first"):
+        return "scan_bits_bf_kernel (W=%d)" % ((info["total_bits"] + 31) // 32)
     return "scan_bits_kernel (W=%d, Qb=%d, ea=%d)" % ((info["total_bits"] + 31) // 32, tm["queries_per_pass"],
                                                        tm["early_abandon"])
 

@@ -495,3 +495,33 @@ def test_add_codes_appends_rows(vaqlib, oracle):
         a = v.search(c["X"], k)
         assert_topk_matches(a.labels.reshape(8, k), a.distances.reshape(8, k), o_lab, o_dis, ad, what="appended")
         v.close()
+
+
+@pytest.mark.parametrize("bits", [[8] * 12, [8] * 8, [12, 10, 9, 8, 8, 7, 6, 4]], ids=["m12", "m8", "nonuniform"])
+def test_best_first_rounds_multislice(vaqlib, oracle, bits):
+    """The best-first form where its rarely taken paths are the normal ones: thousands of tiny
+    buckets (keys continued into the second code), more eligible buckets than one round holds,
+    several slices per query whose workgroups adopt each other's thresholds in mid-setup (found
+    by tools/fuzz_parity.py: a per-wave threshold made the workgroup-wide bisection diverge)."""
+    c = make_case(9917, 4 * len(bits), bits, 4097, 33, dup_frac=0.05)
+    k = 5
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True)
+    ad = oracle_all_dists(oracle, c, Xp)
+    ran = 0
+    for bucket_bits in (8, 9, 10):
+        v = make_index(c)
+        v._ensure_index()
+        v.set_option("bucket_bits", bucket_bits)
+        for slices in (0, 2, 5):
+            v.set_option("slices", slices)
+            v.set_option("early_abandon", 1)
+            v.set_option("waves_per_workgroup", 4)
+            v.set_option("timing", 1)
+            for rep in range(6):
+                a = v.search(c["X"], k)
+                assert_topk_matches(a.labels.reshape(33, k), a.distances.reshape(33, k), o_lab, o_dis, ad,
+                                    what=f"bucket_bits={bucket_bits} slices={slices} rep={rep}")
+            ran += v.last_timing()["best_first"]
+        v.close()
+    assert ran >= 4, ran

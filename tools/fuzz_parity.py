@@ -91,7 +91,22 @@ while time.time() - t0 < budget:
             ties += assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
                                         what=f"M={M} L={L} bits={bits} N={N} nq={nq} k={k} {opts}")
         except AssertionError as e:
-            print("MISMATCH", e); print("case seed info:", M, L, bits, N, nq, k, opts); sys.exit(1)
+            print("MISMATCH", e); print("case seed info:", M, L, bits, N, nq, k, opts)
+            print("timing/plan of the failing search:", v.last_timing(), v.info())
+            # which option matters: flip each one back to its default in turn
+            for key2, dflt in (("best_first", 0), ("best_first", 1), ("ordered_slices", 0), ("slices", 0), ("seed_thresholds", 0),
+                               ("hot_buckets", 16), ("waves_per_workgroup", 0), ("queries_per_pass", 1)):
+                v.set_option(key2, dflt)
+                b2 = v.search(c["X"], k)
+                same = np.array_equal(b2.distances.reshape(nq, k), o_dis)
+                print(f"  with {key2}={dflt}: distances {'match' if same else 'DIFFER'}  plan {v.last_timing()}")
+                v.set_option(key2, opts[key2])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", "fuzz_fail_case.npz"), X=c["X"], codes=c["codes"],
+                     eig=c["eig"] if c["eig"] is not None else np.zeros(0), bits=np.array(bits),
+                     **{f"cent{s_}": c["cents"][s_] for s_ in range(M)}, o_lab=o_lab, o_dis=o_dis,
+                     g_lab=a.labels.reshape(nq, k), g_dis=a.distances.reshape(nq, k))
+            sys.exit(1)
         n_searches += 1
     if n_cases % 3 == 0 and N >= 64 and M % 4 == 0 and sum(1 << b for b in bits) * 4 < 120000:
         # triangle-inequality form on the same rows

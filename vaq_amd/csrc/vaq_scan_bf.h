@@ -44,6 +44,11 @@ constexpr int BF_CB_CAP = BF_FLUSH_AT - 1 + 64; // one drain appends at most 64
 constexpr int BF_RING = VAQ_BF_RING;            // code items in flight per wave (register sets)
 constexpr int BF_QCAP = 128;                    // survivor queue: at most 63 left over + 64 pushed
 constexpr int BF_MAX_BUCKETS = 1024;
+constexpr int VAQ_BF_MAX_SUBS = 128;  // VAQHIP_MAX_SUBSPACES
+#ifndef VAQ_BF_ROUND
+#define VAQ_BF_ROUND 256
+#endif
+constexpr int BF_ROUND_BUCKETS = VAQ_BF_ROUND;  // buckets one round orders and scans
 constexpr int BF_BOOT_STEPS = VAQ_BF_BOOT;      // wave steps each wave samples to bootstrap the threshold (0 = off)
 
 __host__ __device__ inline size_t bf_align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -63,10 +68,12 @@ constexpr int BF_HDR_SCALE = 5;   // header word: float bits of bins / H, 0 = hi
 __host__ __device__ inline int bf_queue_code_words(int M) { return M <= 16 ? M / 4 - 1 : 0; }
 // LDS of one workgroup: [LUT][k-min][sorted bucket keys, row ranges, unit prefix, ticket, gmin]
 // [per wave: survivor queue, candidate buffer]
-__host__ __device__ inline size_t bf_lds_bytes(int lut_entries, int kp, int n_buckets, int nwaves, int qcw) {
-  size_t b = bf_align16((size_t)lut_entries * 4);
+__host__ __device__ inline size_t bf_lds_bytes(int lut_entries, int kp, int n_buckets, int nwaves, int qcw,
+                                               int extra_words) {
+  size_t b = bf_align16((size_t)lut_entries * 4) + bf_align16((size_t)extra_words * 4);
   b += bf_align16((size_t)SEL_HDR_WORDS * 4 + (size_t)bf_pool_cap(kp) * 8) + (size_t)BF_HIST_BINS * 4;
-  b += bf_align16((size_t)n_buckets * 12 + (size_t)(n_buckets + 1) * 4 + 12 + (size_t)(1 << GMIN_MAX_BITS) * 4);
+  b += bf_align16((size_t)BF_ROUND_BUCKETS * 8 + 4 + 32 + (size_t)(1 << GMIN_MAX_BITS) * 4);
+  (void)n_buckets;
   b += (size_t)nwaves * ((size_t)BF_QCAP * 4 * (2 + qcw) + (size_t)BF_CB_CAP * 8);
   return b;
 }
@@ -173,12 +180,182 @@ __device__ __forceinline__ int pool_compact(const SelView &sel, const int n, con
   return w;
 }
 
-template <int M, bool UL0>
-__device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
+// ---------------------------------------------------------------------------
+// Layout policies: what the best-first scaffold needs to know about a code layout.
+//   Item            the registers one lane holds per wave step (ROWS rows)
+//   first_two       A : dism = l0; dism += l1            (l0 wave-uniform when UL0)
+//   rest_of_first   A2: dism += l2; dism += l3            -> the first group's sum
+//   carry / tail    the row's remaining groups, from the words carried through the survivor
+//                   queue (QCW of them) or re-read from the code array; abandons per group
+//   full            the complete row sum (bootstrap sample)
+// Arithmetic order is the reference's throughout (VAQ.cpp:1737-1748).
+// ---------------------------------------------------------------------------
+template <int M> struct BfBytes {
   typedef BytesItem<M> Item;
-  constexpr int WPR = Item::WPR;
-  constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
-  constexpr int WSTEP = 64 * Item::ROWS;  // rows per wave step
+  static constexpr int ROWS = Item::ROWS;
+  static constexpr int WPR = Item::WPR;
+  static constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
+  static constexpr bool HAS_TAIL = WPR > 1;
+  static constexpr int LDS_WORDS = 0;  // no per-workgroup tables besides the LUT
+  const float *lut;
+  __device__ __forceinline__ void init(const ScanParams &, const float *lut_lds, unsigned *, int, int) { lut = lut_lds; }
+  __device__ static __forceinline__ int lut_entries(const ScanParams &) { return M * 256; }
+  __device__ static __forceinline__ void second_table(const ScanParams &, int &off1, int &ncent1) {
+    off1 = 256;
+    ncent1 = 256;
+  }
+  __device__ static __forceinline__ void load(Item &it, const uint32_t *codes, const int base_row, const int lane) {
+    it.load(codes, (int64_t)(base_row / ROWS) + lane);
+  }
+  __device__ __forceinline__ float lut4(const uint32_t c4, const int g) const {
+    float dism = lut[(g * 4 + 0) * 256 + (c4 & 0xffu)];
+    dism = dism + lut[(g * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)];
+    dism = dism + lut[(g * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)];
+    dism = dism + lut[(g * 4 + 3) * 256 + (c4 >> 24)];
+    return dism;
+  }
+  template <bool UL0> __device__ __forceinline__ float first_two(const Item &it, const int r, const float l0) const {
+    const uint32_t c0 = it.word(r, 0);
+    const float first = UL0 ? l0 : lut[c0 & 0xffu];
+    return first + lut[256 + ((c0 >> 8) & 0xffu)];
+  }
+  __device__ __forceinline__ float rest_of_first(const Item &it, const int r, float part) const {
+    const uint32_t c0 = it.word(r, 0);
+    part = part + lut[512 + ((c0 >> 16) & 0xffu)];
+    part = part + lut[768 + (c0 >> 24)];
+    return part;
+  }
+  __device__ static __forceinline__ uint32_t carry(const Item &it, const int r, const int w) { return it.word(r, w + 1); }
+  // cw: the QCW carried words (QCW == 0: the row is re-read from the code array)
+  __device__ __forceinline__ float tail(float acc, const uint32_t *cw, const int rid, const uint32_t *codes,
+                                        const float thr, bool &alive) const {
+#pragma unroll
+    for (int g = 1; g < WPR; g++) {
+      const uint32_t c4 = QCW > 0 ? cw[g - 1] : codes[(int64_t)rid * WPR + g];
+      if (alive) {
+        acc = acc + lut4(c4, g);  // dist += dism
+        alive = !(acc > thr);
+      }
+    }
+    return acc;
+  }
+  __device__ __forceinline__ float full(const Item &it, const int r) const {
+    float acc = lut4(it.word(r, 0), 0);
+#pragma unroll
+    for (int g = 1; g < WPR; g++) acc = acc + lut4(it.word(r, g), g);
+    return acc;
+  }
+};
+
+// Bit-packed rows (LAYOUT_BITS: W dwords per row in planar tiles of 64 rows; any 1..15-bit
+// allocation, M a multiple of 4).  CARRY: every field of the groups after the first lies in the
+// row's last dword, which then rides through the survivor queue (C3: 39 of 64 bits are the
+// first group); otherwise phase B re-reads the row from the tiles.
+template <int W, bool CARRY> struct BfBits {
+  struct Item {
+    uint32_t w[W];
+  };
+  static constexpr int ROWS = 1;
+  static constexpr int QCW = CARRY ? 1 : 0;
+  static constexpr bool HAS_TAIL = true;
+  static constexpr int LDS_WORDS = VAQ_BF_MAX_SUBS;  // one packed descriptor per subspace
+  const float *lut;
+  const unsigned *pd;  // LDS: word | shift << 3 | bits << 8 | lut_off << 12 per subspace
+  int M;
+  unsigned m0;               // mask of the first code
+  unsigned sh1, m1, o1;      // shift / mask / table offset of fields 1..3 (fields 2, 3 may straddle dwords 0-1)
+  unsigned sh2, m2, o2, w2;
+  unsigned sh3, m3, o3, w3;
+  // (the descriptors become readable after the next workgroup barrier)
+  __device__ __forceinline__ void init(const ScanParams &p, const float *lut_lds, unsigned *lds_words, const int tid,
+                                       const int nthreads) {
+    lut = lut_lds;
+    const SubDesc *__restrict__ sub = p.sub;
+    M = p.M;
+    for (int s = tid; s < M; s += nthreads) {
+      const SubDesc x = sub[s];
+      lds_words[s] = (unsigned)x.word | ((unsigned)x.shift << 3) | ((unsigned)x.bits << 8) | ((unsigned)x.lut_off << 12);
+    }
+    pd = lds_words;
+    const SubDesc a = sub[0], b = sub[1], c = sub[2], d = sub[3];
+    m0 = (unsigned)a.ncent - 1u;
+    sh1 = (unsigned)b.shift; m1 = (unsigned)b.ncent - 1u; o1 = (unsigned)b.lut_off;
+    sh2 = (unsigned)c.shift; m2 = (unsigned)c.ncent - 1u; o2 = (unsigned)c.lut_off; w2 = (unsigned)c.word;
+    sh3 = (unsigned)d.shift; m3 = (unsigned)d.ncent - 1u; o3 = (unsigned)d.lut_off; w3 = (unsigned)d.word;
+  }
+  __device__ static __forceinline__ int lut_entries(const ScanParams &p) { return p.lut_floats; }
+  __device__ static __forceinline__ void second_table(const ScanParams &p, int &off1, int &ncent1) {
+    off1 = p.sub[1].lut_off;
+    ncent1 = p.sub[1].ncent;
+  }
+  __device__ static __forceinline__ void load(Item &it, const uint32_t *codes, const int base_row, const int lane) {
+    const uint32_t *tp = codes + (int64_t)(base_row / TILE_ROWS) * (TILE_ROWS * W) + lane;
+#pragma unroll
+    for (int i = 0; i < W; i++) it.w[i] = tp[i * TILE_ROWS];
+  }
+  template <bool UL0> __device__ __forceinline__ float first_two(const Item &it, const int, const float l0) const {
+    const uint32_t w0 = it.w[0];
+    const float first = UL0 ? l0 : lut[w0 & m0];
+    return first + lut[o1 + ((w0 >> sh1) & m1)];  // field 1 lies inside dword 0 (two fields <= 30 bits)
+  }
+  __device__ __forceinline__ float rest_of_first(const Item &it, const int, float part) const {
+    const uint32_t w0 = it.w[0];
+    const uint32_t w1 = W > 1 ? it.w[W > 1 ? 1 : 0] : 0u;
+    const uint32_t c2 = (w2 == 0 ? __builtin_amdgcn_alignbit(w1, w0, sh2) : (w1 >> sh2)) & m2;
+    const uint32_t c3 = (w3 == 0 ? __builtin_amdgcn_alignbit(w1, w0, sh3) : (w1 >> sh3)) & m3;
+    part = part + lut[o2 + c2];
+    part = part + lut[o3 + c3];
+    return part;
+  }
+  __device__ static __forceinline__ uint32_t carry(const Item &it, const int, const int) { return it.w[W - 1]; }
+  // subspaces [s_from, M) of a row given as words: dism = l; dism += l x3; dist += dism per group
+  template <typename GetWord>
+  __device__ __forceinline__ float chain(float acc, const int s_from, GetWord word, const float thr, bool &alive,
+                                         const bool ea) const {
+    float dism = 0.0f;
+    for (int s = s_from; s < M; s++) {
+      const unsigned d = pd[s];
+      if (!ea || alive) {
+        const int wd = (int)(d & 7u);
+        const uint32_t lo = word(wd);
+        const uint32_t hi = wd + 1 < W ? word(wd + 1) : 0u;
+        const uint32_t c = __builtin_amdgcn_alignbit(hi, lo, (d >> 3) & 31u) & ((1u << ((d >> 8) & 15u)) - 1u);
+        const float l = lut[(d >> 12) + c];
+        dism = (s & 3) == 0 ? l : dism + l;
+        if ((s & 3) == 3) {
+          acc = s == 3 ? dism : acc + dism;
+          if (ea) alive = !(acc > thr);
+        }
+      }
+    }
+    return acc;
+  }
+  __device__ __forceinline__ float tail(float acc, const uint32_t *cw, const int rid, const uint32_t *codes,
+                                        const float thr, bool &alive) const {
+    if (CARRY) {
+      const uint32_t last = cw[0];
+      return chain(acc, 4, [&](const int) -> uint32_t { return last; }, thr, alive, true);
+    }
+    const uint32_t *rp = codes + (int64_t)(rid / TILE_ROWS) * (TILE_ROWS * W) + (rid % TILE_ROWS);
+    return chain(acc, 4, [&](const int w) -> uint32_t { return rp[w * TILE_ROWS]; }, thr, alive, true);
+  }
+  __device__ __forceinline__ float full(const Item &it, const int) const {
+    bool alive = true;
+    return chain(0.0f, 0, [&](const int w) -> uint32_t {
+      uint32_t x = it.w[0];
+#pragma unroll
+      for (int i = 1; i < W; i++) x = (w == i) ? it.w[i] : x;
+      return x;
+    }, FLT_MAX, alive, false);
+  }
+};
+
+template <typename Pol, bool UL0>
+__device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
+  typedef typename Pol::Item Item;
+  constexpr int ROWS = Pol::ROWS;
+  constexpr int QCW = Pol::QCW;
+  constexpr int WSTEP = 64 * ROWS;  // rows per wave step
   constexpr int SEG_ROWS = BF_SEG_STEPS * WSTEP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -200,22 +377,27 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
 
   // ---- LDS carve-up (bf_lds_bytes) ----
   float *lut = reinterpret_cast<float *>(smem);
-  size_t off = bf_align16((size_t)M * 256 * 4);
+  const int lut_entries = Pol::lut_entries(p);
+  size_t off = bf_align16((size_t)lut_entries * 4);
+  unsigned *pol_words = reinterpret_cast<unsigned *>(smem + off);
+  off += bf_align16((size_t)Pol::LDS_WORDS * 4);
   const int cap = bf_pool_cap(kp);
   const SelView sel = sel_view(smem + off, cap, 0);
   off += bf_align16((size_t)SEL_HDR_WORDS * 4 + (size_t)cap * 8);
   unsigned *hist = reinterpret_cast<unsigned *>(smem + off);  // [64] admitted rows per distance bin
   off += (size_t)BF_HIST_BINS * 4;
-  unsigned *keys = reinterpret_cast<unsigned *>(smem + off);  // [K0] sorted: bound bits | bucket
-  int *s0a = reinterpret_cast<int *>(keys + K0);              // [K0] first row of the i-th best bucket
-  int *e0a = s0a + K0;                                        // [K0] one past its last row (inside the slice)
-  int *cum = e0a + K0;                                        // [K0 + 1] prefix of work units
-  unsigned *ticket = reinterpret_cast<unsigned *>(cum + K0 + 1);
-  unsigned *boot_cnt = ticket + 1;                            // bootstrap: rows counted below boot_thr
-  unsigned *boot_thr = ticket + 2;                            //            float bits, max over the waves
-  unsigned *gmin = ticket + 3;                                // [1 << bt] smallest second term per group
-  off += bf_align16((size_t)K0 * 12 + (size_t)(K0 + 1) * 4 + 12 + (size_t)(1 << GMIN_MAX_BITS) * 4);
-  unsigned *ktmp = reinterpret_cast<unsigned *>(smem + off);  // [K0] unsorted keys: borrows the waves' buffers
+  // the buckets a round works through: at most BF_ROUND_BUCKETS of them, nearest first
+  unsigned *keys = reinterpret_cast<unsigned *>(smem + off);  // [BF_ROUND_BUCKETS] sorted: bound bits | bucket
+  int *cum = reinterpret_cast<int *>(keys + BF_ROUND_BUCKETS); // [BF_ROUND_BUCKETS + 1] prefix of work units
+  unsigned *ticket = reinterpret_cast<unsigned *>(cum + BF_ROUND_BUCKETS + 1);
+  unsigned *boot_cnt = ticket + 1;   // bootstrap: rows counted below boot_thr
+  unsigned *boot_thr = ticket + 2;   //            float bits, max over the waves
+  unsigned *sh_min = ticket + 3;     // smallest key (the nearest bucket)
+  unsigned *sh_cnt = ticket + 4;     // buckets eligible for the round
+  unsigned *sh_rot = ticket + 5;     // [3] counters of the overflow bisection
+  unsigned *gmin = ticket + 8;       // [1 << bt] smallest second term per group
+  off += bf_align16((size_t)BF_ROUND_BUCKETS * 8 + 4 + 32 + (size_t)(1 << GMIN_MAX_BITS) * 4);
+  unsigned *kuns = reinterpret_cast<unsigned *>(smem + off);  // [BF_ROUND_BUCKETS] unsorted: borrows the waves' buffers
   unsigned char *wb = smem + off + (size_t)wave * ((size_t)BF_QCAP * 4 * (2 + QCW) + (size_t)BF_CB_CAP * 8);
   int *q_id = reinterpret_cast<int *>(wb);
   float *q_p = reinterpret_cast<float *>(q_id + BF_QCAP);
@@ -231,7 +413,10 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
   // ---- setup ----
   const float *__restrict__ glut = p.lut + (size_t)qi * p.lut_floats;
   const int *__restrict__ bstart = p.bucket_start;
-  for (int e = tid; e < M * 256; e += nthreads) lut[e] = glut[e];
+  const int nwaves = nthreads >> 6;
+  for (int e = tid; e < lut_entries; e += nthreads) lut[e] = glut[e];
+  Pol pol;
+  pol.init(p, lut, pol_words, tid, nthreads);  // (its LDS tables are complete after the barriers below)
   if (tid == 0) {
     unsigned td = float_to_bits(FLT_MAX);
     int ti = INT_MIN;
@@ -245,78 +430,65 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
     sel.hdr[SEL_THR_D] = td;
     sel.hdr[SEL_THR_ID] = (unsigned)ti;
     sel.hdr[BF_HDR_SCALE] = 0u;
-    *ticket = 0u;
+    *boot_cnt = 0u;
+    *boot_thr = 0u;
+    *sh_min = 0xffffffffu;
     cum[0] = 0;
   }
+  if (tid < BF_HIST_BINS) hist[tid] = 0u;
   if (bt > 0) {  // the bucket key continues into the second code: its groups' smallest terms
     for (int i = tid; i < (1 << bt); i += nthreads) gmin[i] = 0x7f800000u;
     __syncthreads();
-    const int w = 8 - bt;  // log2 of the group size (second code: 8 bits)
-    for (int e = tid; e < 256; e += nthreads) atomicMin(&gmin[e >> w], float_to_bits(glut[256 + e]));
-    __syncthreads();
+    int off1, ncent1;
+    Pol::second_table(p, off1, ncent1);
+    const int w = 31 - __builtin_clz((unsigned)ncent1) - bt;  // log2 of the group size
+    for (int e = tid; e < ncent1; e += nthreads) atomicMin(&gmin[e >> w], float_to_bits(glut[off1 + e]));
   }
-  // one packed word per bucket: lower bound of its row sums (low bits cut: still a lower bound) |
-  // bucket -- unique, so ranks are positions.  Empty buckets and NaN tables sort last.
+  __syncthreads();
+  // One packed word per bucket: lower bound of its row sums (low bits cut: still a lower bound) |
+  // bucket -- unique.  Empty buckets and NaN tables get the largest keys and are never eligible.
   const unsigned empty_key = ~idx_mask;
-  for (int b = tid; b < K0; b += nthreads) {
-    unsigned key = empty_key | (unsigned)b;
+  auto bucket_key = [&](const int b) -> unsigned {
     const int s0 = bstart[b] > r0 ? bstart[b] : r0;
     const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
-    if (e0 > s0) {
-      float m;
-      if (bt > 0) {
-        m = glut[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
-      } else {
-        m = INFINITY;
-        for (int c = b << bshift; c < ((b + 1) << bshift); c++) {
-          const float x = glut[c];
-          m = x < m ? x : m;
-        }
+    if (e0 <= s0) return empty_key | (unsigned)b;
+    float m;
+    if (bt > 0) {
+      m = glut[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
+    } else {
+      m = INFINITY;
+      for (int c = b << bshift; c < ((b + 1) << bshift); c++) {
+        const float x = glut[c];
+        m = x < m ? x : m;
       }
-      if (m == m) key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
     }
-    ktmp[b] = key;
-  }
-  if (tid == 0) {
-    *boot_cnt = 0u;
-    *boot_thr = 0u;
-  }
-  if (tid < BF_HIST_BINS) hist[tid] = 0u;
-  __syncthreads();
-  // rank sort: position = number of smaller keys (every lane reads the same words: LDS broadcasts)
+    if (!(m == m)) return empty_key | (unsigned)b;
+    return (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
+  };
+  auto units_of = [&](const unsigned key) -> int {
+    const int b = (int)(key & idx_mask);
+    const int s0 = bstart[b] > r0 ? bstart[b] : r0;
+    const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+    return (e0 - (s0 & ~(WSTEP - 1)) + SEG_ROWS - 1) / SEG_ROWS;
+  };
+  // every bucket's key, kept in LDS (the waves' buffers, not yet in use) until the first round has
+  // picked its buckets; a thread only ever reads back the entries it wrote
+  unsigned *kall = kuns + BF_ROUND_BUCKETS;  // [K0]
+  unsigned km0 = 0xffffffffu;
+#pragma unroll 1
   for (int b = tid; b < K0; b += nthreads) {
-    const unsigned key = ktmp[b];
-    int rank = 0;
-    for (int j = 0; j < K0; j += 4) {
-      const uint4 o = *reinterpret_cast<const uint4 *>(ktmp + j);  // K0 is a power of two >= 16
-      rank += (o.x < key) + (o.y < key) + (o.z < key) + (o.w < key);
-    }
-    int s0 = 0, e0 = 0, units = 0;
-    if ((key & empty_key) != empty_key) {
-      s0 = bstart[b] > r0 ? bstart[b] : r0;
-      e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
-      units = (e0 - (s0 & ~(WSTEP - 1)) + SEG_ROWS - 1) / SEG_ROWS;
-    }
-    keys[rank] = key;
-    s0a[rank] = s0;
-    e0a[rank] = e0;
-    cum[rank + 1] = units;
+    const unsigned key = bucket_key(b);
+    kall[b] = key;
+    km0 = key < km0 ? key : km0;
   }
-  __syncthreads();
-  if (wave == 0) {  // inclusive prefix of the unit counts, 64 at a time
-    int carry = 0;
-    for (int base = 0; base < K0; base += 64) {
-      const int i = base + lane;
-      const int u = i < K0 ? cum[i + 1] : 0;
-      int inc = u;
+  {  // the nearest bucket (smallest key)
+    unsigned km = km0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int x = __shfl_up(inc, o);
-        if (lane >= o) inc += x;
-      }
-      if (i < K0) cum[i + 1] = carry + inc;
-      carry += __builtin_amdgcn_readlane(inc, 63);
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned x = (unsigned)__shfl_xor((int)km, o);
+      km = x < km ? x : km;
     }
+    if (lane == 0) atomicMin(sh_min, km);
   }
   __syncthreads();
 #ifdef VAQ_STATS
@@ -439,14 +611,6 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
     if (ccnt >= BF_FLUSH_AT) flush();
   };
 
-  auto lut4 = [&](const uint32_t c4, const int g) -> float {  // dism = l0; dism += l1; dism += l2; dism += l3
-    float dism = lut[(g * 4 + 0) * 256 + (c4 & 0xffu)];
-    dism = dism + lut[(g * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)];
-    dism = dism + lut[(g * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)];
-    dism = dism + lut[(g * 4 + 3) * 256 + (c4 >> 24)];
-    return dism;
-  };
-
   // phase B: the top n (<= 64) queue entries, one per lane: groups 1.. of the row, abandoning
   // after each (VAQ.cpp:1708)
   auto drain = [&](const int n) {
@@ -458,14 +622,10 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
     const int rid = q_id[slot];
     float acc = q_p[slot];
     bool alive = ok;
+    uint32_t cw[QCW > 0 ? QCW : 1];
 #pragma unroll
-    for (int g = 1; g < WPR; g++) {
-      const uint32_t cw = QCW > 0 ? q_cw[(g - 1) * BF_QCAP + slot] : codes[(int64_t)rid * WPR + g];
-      if (alive) {
-        acc = acc + lut4(cw, g);  // dist += dism
-        alive = !(acc > thr_d);
-      }
-    }
+    for (int w = 0; w < QCW; w++) cw[w] = q_cw[w * BF_QCAP + slot];
+    acc = pol.tail(acc, cw, rid, codes, thr_d, alive);
     STAT_T1(ST_CYC_DRAIN, t_dr);
     gather(acc, rid, alive);
   };
@@ -476,41 +636,36 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
     return __builtin_amdgcn_readfirstlane(t);
   };
 
-  const int total_units = cum[K0];
   // ---- bootstrap: a first threshold from the rows nearest the query ----
-  // Wave w sums the rows of the first BF_BOOT_STEPS steps of work unit w completely (the
-  // nearest buckets come first) and every lane keeps the smallest distance it saw: 64 distinct
-  // rows per wave.  With q = ceil(k / waves), the q-th smallest of a wave's 64 vouches for q
-  // rows at or below it, so the largest of the waves' values has at least k rows at or below
-  // it: an upper bound of the final k-th distance, i.e. a valid admission threshold (with
-  // label INT_MAX: rows AT that distance stay admissible).  Without it every wave's first
-  // steps pass every row and the waves queue up on the lock folding them.
-  if (BF_BOOT_STEPS > 0 && !p.no_skip) {
-    const int nwaves = nthreads >> 6;
-    const int q = (k + nwaves - 1) / nwaves;
-    if (q <= 64 && wave < total_units) {
-      int i = 0;
-      while (cum[i + 1] <= wave) i++;
-      const int bs = s0a[i], bend = e0a[i];
-      const int j = wave - cum[i];
-      const int al = bs & ~(WSTEP - 1);
-      int pos = al + j * SEG_ROWS;
-      if (pos < bs) pos = bs;
-      int be = al + (j + 1) * SEG_ROWS;
-      if (be > bend) be = bend;
-      const int base0 = pos & ~(WSTEP - 1);
+  // The waves sum BF_BOOT_STEPS steps each of the nearest bucket's rows completely and every lane
+  // keeps the smallest distance it saw: 64 distinct rows per wave.  With q = ceil(k / sampling
+  // waves), the q-th smallest of a wave's 64 vouches for q rows at or below it, so the largest of
+  // the waves' values has at least k rows at or below it: an upper bound of the final k-th
+  // distance, i.e. a valid admission threshold (with label INT_MAX: rows AT that distance stay
+  // admissible).  It also bounds which buckets can matter at all (below).
+  const unsigned kmin = *sh_min;
+  if (BF_BOOT_STEPS > 0 && !p.no_skip && (kmin & empty_key) != empty_key) {
+    const int bb = (int)(kmin & idx_mask);
+    const int bs = bstart[bb] > r0 ? bstart[bb] : r0;
+    const int bend = bstart[bb + 1] < r1 ? bstart[bb + 1] : r1;
+    const int base00 = bs & ~(WSTEP - 1);
+    const int steps = (bend - base00 + WSTEP - 1) / WSTEP;
+    int pw = (steps + BF_BOOT_STEPS - 1) / BF_BOOT_STEPS;  // waves that get rows to sample
+    pw = pw < nwaves ? pw : nwaves;
+    const int q = (k + pw - 1) / pw;
+    if (q <= 64 && wave < pw) {
+      const int pos = bs, be = bend;
+      const int base0 = base00 + wave * BF_BOOT_STEPS * WSTEP;
       int nst = (be - base0 + WSTEP - 1) / WSTEP;
       if (nst > BF_BOOT_STEPS) nst = BF_BOOT_STEPS;
       float best = INFINITY;
       for (int st = 0; st < nst; st++) {
         Item cur;
-        cur.load(codes, (int64_t)((base0 + st * WSTEP) / Item::ROWS) + lane);
+        Pol::load(cur, codes, base0 + st * WSTEP, lane);
 #pragma unroll
-        for (int r = 0; r < Item::ROWS; r++) {
-          const int row = base0 + st * WSTEP + lane * Item::ROWS + r;
-          float acc = lut4(cur.word(r, 0), 0);
-#pragma unroll
-          for (int g = 1; g < WPR; g++) acc = acc + lut4(cur.word(r, g), g);
+        for (int r = 0; r < ROWS; r++) {
+          const int row = base0 + st * WSTEP + lane * ROWS + r;
+          const float acc = pol.full(cur, r);
           if (row >= pos && row < be && acc < best) best = acc;
         }
       }
@@ -531,117 +686,267 @@ __device__ __forceinline__ void scan_bytes_bf_body(const ScanParams &p) {
       }
     }
     __syncthreads();
+#ifdef VAQ_BF_DBG_PRINT
+    if (tid == 0 && qi == 8)
+      printf("[boot] slice %d kmin %08x bucket %d rows [%d,%d) cnt %u thr %g hdr %g\n", slice, kmin, (int)(kmin & idx_mask),
+             bs, bend, *boot_cnt, bits_to_float(*boot_thr), bits_to_float(sel.hdr[SEL_THR_D]));
+#endif
     if (tid == 0 && *boot_cnt >= (unsigned)k) {
       const unsigned tb = *boot_thr;
       if (tb < sel.hdr[SEL_THR_D]) {
         sel.hdr[SEL_THR_D] = tb;
         sel.hdr[SEL_THR_ID] = (unsigned)INT_MAX;
+#ifndef VAQ_BF_NO_BOOT_PUBLISH
+#ifdef VAQ_BF_PUB_LOOSE
+        if (multi_slice) atomicMin(&p.g_thr[qi], float_to_bits(bits_to_float(tb) * 1.5f));
+#else
         if (multi_slice) atomicMin(&p.g_thr[qi], tb);
+#endif
+#endif
       }
       // histogram over [0, H], H = the threshold every admitted row is at or below from now on
       const float H = bits_to_float(sel.hdr[SEL_THR_D]);
+#ifndef VAQ_BF_NO_HIST
       if (H > 0.0f && H < FLT_MAX) sel.hdr[BF_HDR_SCALE] = float_to_bits((float)BF_HIST_BINS / H);
+#endif
     }
     __syncthreads();
   }
   refresh(0);  // the bootstrapped / seeded / already published threshold, before the first bound is tested
-  // window of the unit prefix in registers: lane j holds cum[wbase + j + 1]
-  int wbase = 0;
-  int creg = (lane + 1 <= K0) ? cum[lane + 1] : INT_MAX;
-  int t = take_ticket();
-  while (t < total_units) {
-    const int t_next = take_ticket();  // (its LDS round trip overlaps this unit's work)
-    STAT_ADD(ST_BUCKETS_TESTED, 1);
-    int cnt;
-    for (;;) {  // i = largest index with cum[i] <= t
-      cnt = __popcll(__ballot(creg <= t));
-      if (cnt < 64) break;
-      wbase += 64;
-      creg = (wbase + lane + 1 <= K0) ? cum[wbase + lane + 1] : INT_MAX;
+  // ---- rounds: the eligible buckets (bound not above the threshold, not done yet), nearest first,
+  //      at most BF_ROUND_BUCKETS per round; thresholds fall while a round runs, so a second round
+  //      is rarely anything but the check that nothing is left ----
+  bool first_round = true;
+  unsigned done_key = 0u;  // buckets with keys <= done_key are finished (after the first round)
+  for (;;) {
+    if (tid == 0) *sh_cnt = 0u;
+    __syncthreads();
+    // the round's threshold must be the SAME for every thread (the bisection below is a workgroup-
+    // wide loop): read it from LDS between two barriers, where nothing scans and nothing moves it
+    thr_d = bits_to_float(sel.hdr[SEL_THR_D]);
+    const unsigned thr_bits = p.no_skip ? 0x7f800000u : float_to_bits(thr_d);
+    auto eligible = [&](const unsigned key) -> bool {
+      return (key & empty_key) != empty_key && (first_round || key > done_key) && (key & ~idx_mask) <= thr_bits;
+    };
+    unsigned hi_key = 0xffffffffu;  // (only keys <= hi_key join this round)
+    if (!first_round) {
+#pragma unroll 1
+      for (int b = tid; b < K0; b += nthreads) kall[b] = bucket_key(b);
     }
-    const int i = wbase + cnt;
-    const unsigned key = (unsigned)__builtin_amdgcn_readfirstlane((int)keys[i]);
-    const float lbv = bits_to_float(key & ~idx_mask);
-    // buckets come in ascending order of their bound and thresholds only fall: nothing
-    // from here on can hold an admissible row
-    if (!p.no_skip && lbv > thr_d) break;
-    STAT_ADD(ST_BUCKETS_VISITED, 1);
-    const int b = (int)(key & idx_mask);
-    const int bs = __builtin_amdgcn_readfirstlane(s0a[i]);
-    const int bend = __builtin_amdgcn_readfirstlane(e0a[i]);
-    const int j = t - __builtin_amdgcn_readfirstlane(cum[i]);
-    const int al = bs & ~(WSTEP - 1);
-    int pos = al + j * SEG_ROWS;
-    if (pos < bs) pos = bs;
-    int be = al + (j + 1) * SEG_ROWS;
-    if (be > bend) be = bend;
-    // the rows' shared first term (fine buckets)
-    const float l0 = UL0 ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[b >> bt]))) : 0.0f;
-    const int base0 = pos & ~(WSTEP - 1);
-    const int nst = (be - base0 + WSTEP - 1) / WSTEP;
-    const int64_t item0 = (int64_t)(base0 / Item::ROWS) + lane;
-
-    auto step = [&](const Item &cur, const int st) {
-      const int base = base0 + st * WSTEP;
-      STAT_ADD(ST_STEPS, 1);
-      refresh(stepno++);
-      const bool interior = base >= pos && base + WSTEP <= be;  // wave-uniform: no per-row range test
-      const int row0 = base + lane * Item::ROWS;
-      float part[Item::ROWS];
-      bool alive[Item::ROWS];
-#pragma unroll
-      for (int r = 0; r < Item::ROWS; r++) {
-        const uint32_t c0 = cur.word(r, 0);
-        // A: dism = l0; dism += l1
-        const float first = UL0 ? l0 : lut[c0 & 0xffu];
-        part[r] = first + lut[256 + ((c0 >> 8) & 0xffu)];
-        alive[r] = !(part[r] > thr_d);
-        if (!interior) alive[r] = alive[r] && (row0 + r >= pos) && (row0 + r < be);
-        STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
+#pragma unroll 1
+    for (int b = tid; b < K0; b += nthreads) {
+      const unsigned key = kall[b];
+      if (eligible(key)) {
+        const unsigned pos = atomicAdd(sh_cnt, 1u);
+        if (pos < (unsigned)BF_ROUND_BUCKETS) kuns[pos] = key;
       }
-#pragma unroll
-      for (int r = 0; r < Item::ROWS; r++) {
-        bool live = alive[r];
-        if (live) {  // A2: dism += l2; dism += l3 -> the first group's sum
-          const uint32_t c0 = cur.word(r, 0);
-          part[r] = part[r] + lut[512 + ((c0 >> 16) & 0xffu)];
-          part[r] = part[r] + lut[768 + (c0 >> 24)];
-          live = !(part[r] > thr_d);
+    }
+    __syncthreads();
+    int n = (int)*sh_cnt;
+#ifdef VAQ_BF_DBG_PRINT
+    if (lane == 0 && qi == 8) printf("[round] slice %d wave %d n %d thr_d %g first %d\n", slice, wave, n, thr_d, (int)first_round);
+#endif
+    if (n == 0) break;
+    STAT_ADD(ST_FOLDS, n);
+    if (n > BF_ROUND_BUCKETS) {
+      // more eligible buckets than a round holds (weak or no bootstrap threshold): bisect for the
+      // largest key bound that lets at most BF_ROUND_BUCKETS of them in
+      // (any bound that lets between half a round and a whole round in will do; three counters
+      //  in rotation: one barrier per step)
+      unsigned lo = 0u, hi = thr_bits | idx_mask;  // count(key <= lo) <= cap is maintained
+      __syncthreads();
+      if (tid == 0) { sh_rot[0] = 0u; sh_rot[1] = 0u; sh_rot[2] = 0u; }
+      __syncthreads();
+      int it = 0;
+      while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1) + 1u;  // upper middle: lo < mid <= hi
+        int c = 0;
+#pragma unroll 1
+        for (int b = tid; b < K0; b += nthreads) {
+          const unsigned key = kall[b];
+          c += (eligible(key) && key <= mid) ? 1 : 0;
         }
-        STAT_ADD(ST_ALIVE_A2, __popcll(__ballot(live)));
-        if (WPR == 1) {  // (M = 4 would end here; kept for completeness)
-          gather(part[r], row0 + r, live);
+        unsigned *cur = sh_rot + (it % 3);
+        if (c) atomicAdd(cur, (unsigned)c);
+        if (tid == 0) sh_rot[(it + 1) % 3] = 0u;  // (last read two steps ago)
+        __syncthreads();
+        const int tot = (int)*cur;
+        it++;
+        if (tot <= BF_ROUND_BUCKETS) {
+          lo = mid;
+          if (tot >= BF_ROUND_BUCKETS / 2) break;
         } else {
-          const unsigned long long m = __ballot(live);
-          if (m != 0ull) {
-            const int qp = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (live) {
-              q_id[qp] = row0 + r;
-              q_p[qp] = part[r];
+          hi = mid - 1u;
+        }
+      }
+      hi_key = lo;
+      __syncthreads();
+      if (tid == 0) *sh_cnt = 0u;
+      __syncthreads();
+#pragma unroll 1
+      for (int b = tid; b < K0; b += nthreads) {
+        const unsigned key = kall[b];
+        if (eligible(key) && key <= hi_key) kuns[atomicAdd(sh_cnt, 1u)] = key;
+      }
+      __syncthreads();
+      n = (int)*sh_cnt;  // >= 1: keys are unique, so the smallest eligible key alone always fits
+    }
+    // rank sort (n <= BF_ROUND_BUCKETS): position = number of smaller keys
+    for (int i = tid; i < n; i += nthreads) {
+      const unsigned key = kuns[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += kuns[j] < key ? 1 : 0;
+      keys[rank] = key;
+      cum[rank + 1] = units_of(key);
+    }
+    if (tid == 0) *ticket = 0u;
+    __syncthreads();
+    if (wave == 0) {  // inclusive prefix of the unit counts, 64 at a time
+      int carry = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const int u = i < n ? cum[i + 1] : 0;
+        int inc = u;
 #pragma unroll
-              for (int w = 0; w < QCW; w++) q_cw[w * BF_QCAP + qp] = cur.word(r, w + 1);
+        for (int o = 1; o < 64; o <<= 1) {
+          const int x = __shfl_up(inc, o);
+          if (lane >= o) inc += x;
+        }
+        if (i < n) cum[i + 1] = carry + inc;
+        carry += __builtin_amdgcn_readlane(inc, 63);
+      }
+    }
+    __syncthreads();
+    const int total_units = cum[n];
+    // window of the unit prefix in registers: lane j holds cum[wbase + j + 1]
+    int wbase = 0;
+    int creg = (lane + 1 <= n) ? cum[lane + 1] : INT_MAX;
+    // A unit's description -- sorted position, key, the bucket's row range -- is fetched one unit
+    // ahead: the ticket's LDS round trip and the two reads of bucket_start (global memory) overlap
+    // the scan of the unit before.
+    auto locate = [&](const int t, int &i, unsigned &key, int &bs_raw, int &be_raw) {
+      int cnt;
+      for (;;) {  // i = largest index with cum[i] <= t (tickets only grow: the window moves forward)
+        cnt = __popcll(__ballot(creg <= t));
+        if (cnt < 64) break;
+        wbase += 64;
+        creg = (wbase + lane + 1 <= n) ? cum[wbase + lane + 1] : INT_MAX;
+      }
+      i = wbase + cnt;
+      key = (unsigned)__builtin_amdgcn_readfirstlane((int)keys[i]);
+      const int b = (int)(key & idx_mask);
+      bs_raw = bstart[b];
+      be_raw = bstart[b + 1];
+    };
+    int t = take_ticket();
+    int i = 0, bs_raw = 0, be_raw = 0;
+    unsigned key = 0u;
+    if (t < total_units) locate(t, i, key, bs_raw, be_raw);
+    while (t < total_units) {
+      const int t_next = take_ticket();
+      STAT_ADD(ST_BUCKETS_TESTED, 1);
+      const float lbv = bits_to_float(key & ~idx_mask);
+      // buckets come in ascending order of their bound and thresholds only fall: nothing
+      // from here on can hold an admissible row
+#ifndef VAQ_BF_DBG_NOBREAK
+      if (!p.no_skip && lbv > thr_d) break;
+#endif
+      STAT_ADD(ST_BUCKETS_VISITED, 1);
+      const int b = (int)(key & idx_mask);
+      const int bs = __builtin_amdgcn_readfirstlane(bs_raw > r0 ? bs_raw : r0);
+      const int bend = __builtin_amdgcn_readfirstlane(be_raw < r1 ? be_raw : r1);
+      const int j = t - __builtin_amdgcn_readfirstlane(cum[i]);
+      const int al = bs & ~(WSTEP - 1);
+      int pos = al + j * SEG_ROWS;
+      if (pos < bs) pos = bs;
+      int be = al + (j + 1) * SEG_ROWS;
+      if (be > bend) be = bend;
+      // the rows' shared first term (fine buckets)
+      const float l0 = UL0 ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[b >> bt]))) : 0.0f;
+      const int base0 = pos & ~(WSTEP - 1);
+      const int nst = (be - base0 + WSTEP - 1) / WSTEP;
+      int i_n = 0, bs_n = 0, be_n = 0;
+      unsigned key_n = 0u;
+      if (t_next < total_units) locate(t_next, i_n, key_n, bs_n, be_n);
+
+      auto step = [&](const Item &cur, const int st) {
+        const int base = base0 + st * WSTEP;
+        STAT_ADD(ST_STEPS, 1);
+        refresh(stepno++);
+        const bool interior = base >= pos && base + WSTEP <= be;  // wave-uniform: no per-row range test
+        const int row0 = base + lane * ROWS;
+        float part[ROWS];
+        bool alive[ROWS];
+  #pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          part[r] = pol.template first_two<UL0>(cur, r, l0);  // A: dism = l0; dism += l1
+          alive[r] = !(part[r] > thr_d);
+          if (!interior) alive[r] = alive[r] && (row0 + r >= pos) && (row0 + r < be);
+          STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
+        }
+  #pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          bool live = alive[r];
+          if (live) {  // A2: dism += l2; dism += l3 -> the first group's sum
+            part[r] = pol.rest_of_first(cur, r, part[r]);
+            live = !(part[r] > thr_d);
+          }
+          STAT_ADD(ST_ALIVE_A2, __popcll(__ballot(live)));
+          if (!Pol::HAS_TAIL) {  // (a row of one group ends here)
+            gather(part[r], row0 + r, live);
+          } else {
+            const unsigned long long m = __ballot(live);
+            if (m != 0ull) {
+              const int qp = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+              if (live) {
+                q_id[qp] = row0 + r;
+                q_p[qp] = part[r];
+  #pragma unroll
+                for (int w = 0; w < QCW; w++) q_cw[w * BF_QCAP + qp] = Pol::carry(cur, r, w);
+              }
+              qcnt += __popcll(m);
+              if (qcnt >= 64) drain(64);
             }
-            qcnt += __popcll(m);
-            if (qcnt >= 64) drain(64);
+          }
+        }
+      };
+
+      Item ring[BF_RING];
+  #pragma unroll
+      for (int u = 0; u < BF_RING; u++)
+        if (u < nst) Pol::load(ring[u], codes, base0 + u * WSTEP, lane);
+      for (int st = 0; st < nst; st += BF_RING) {
+  #pragma unroll
+        for (int u = 0; u < BF_RING; u++) {
+          if (st + u < nst) {
+            step(ring[u], st + u);
+            if (st + u + BF_RING < nst) Pol::load(ring[u], codes, base0 + (st + u + BF_RING) * WSTEP, lane);
           }
         }
       }
-    };
-
-    Item ring[BF_RING];
-#pragma unroll
-    for (int u = 0; u < BF_RING; u++)
-      if (u < nst) ring[u].load(codes, item0 + (int64_t)u * 64);
-    for (int st = 0; st < nst; st += BF_RING) {
-#pragma unroll
-      for (int u = 0; u < BF_RING; u++) {
-        if (st + u < nst) {
-          step(ring[u], st + u);
-          if (st + u + BF_RING < nst) ring[u].load(codes, item0 + (int64_t)(st + u + BF_RING) * 64);
-        }
-      }
+      t = t_next;
+      i = i_n;
+      key = key_n;
+      bs_raw = bs_n;
+      be_raw = be_n;
     }
-    t = t_next;
+    // the round's buckets are done (or out of reach); empty the wave's buffers, which the next
+    // round's key list borrows
+#ifndef VAQ_BF_DBG_ALLROUNDS
+    if (hi_key != 0xffffffffu)
+#endif
+    {
+      while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
+      while (ccnt > 0) flush();
+    }
+    __syncthreads();
+    // Every eligible bucket was in this round and thresholds only fall: nothing is left.
+#ifndef VAQ_BF_DBG_ALLROUNDS
+    if (hi_key == 0xffffffffu) break;
+#endif
+    done_key = keys[n - 1];
+    first_round = false;
+    refresh(0);
   }
   STAT_T0(t_tail);
   while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);

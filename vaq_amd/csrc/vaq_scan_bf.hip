@@ -4,38 +4,72 @@
 namespace vaq {
 
 // UL0: every row of a bucket shares its first term (bucket key = the whole first code)
+// (72 VGPRs: seven waves per SIMD, what seven 4-wave workgroups per CU need)
+#ifndef VAQ_BF_VGPRS
+#define VAQ_BF_VGPRS 72  // (informative: waves_per_eu(7, 8) below is what enforces it)
+#endif
+#define VAQ_BF_VGPR_CAP __attribute__((amdgpu_waves_per_eu(7, 8)))
 template <int M, bool UL0>
-__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS void scan_bytes_bf_kernel(ScanParams p) {
-  scan_bytes_bf_body<M, UL0>(p);
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS VAQ_BF_VGPR_CAP void scan_bytes_bf_kernel(ScanParams p) {
+  scan_bf_body<BfBytes<M>, UL0>(p);
+}
+// bit-packed rows of W dwords; CARRY: the row's last dword rides through the survivor queue
+template <int W, bool CARRY, bool UL0>
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS VAQ_BF_VGPR_CAP void scan_bits_bf_kernel(ScanParams p) {
+  scan_bf_body<BfBits<W, CARRY>, UL0>(p);
 }
 
-int scan_bf_max_buckets() { return BF_MAX_BUCKETS; }
+int scan_bf_queue_words(int layout, int M, int bf_carry) {
+  return layout == LAYOUT_BYTES ? bf_queue_code_words(M) : (bf_carry ? 1 : 0);
+}
 
-size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int k, int nwaves, int n_buckets) {
+size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int k, int nwaves, int n_buckets, int bf_carry) {
   int kp = 1;
   while (kp < k) kp <<= 1;
-  if (layout == LAYOUT_BYTES) return bf_lds_bytes(M * 256, kp, n_buckets, nwaves, bf_queue_code_words(M));
-  return bf_lds_bytes(lut_entries, kp, n_buckets, nwaves, 0);
+  return bf_lds_bytes(layout == LAYOUT_BYTES ? M * 256 : lut_entries, kp, n_buckets, nwaves,
+                      scan_bf_queue_words(layout, M, bf_carry), layout == LAYOUT_BYTES ? 0 : VAQ_BF_MAX_SUBS);
 }
 
-// work units of a slice must fit the 31-bit ticket: always true (rows < 2^31)
 bool scan_bf_supported(int layout, int M, int qb, int ea, int n_buckets, int seq) {
-  if (layout != LAYOUT_BYTES) return false;
-  return qb == 1 && ea == EA_QUEUE && !seq && n_buckets >= 2 && n_buckets <= BF_MAX_BUCKETS;
+  if (layout == LAYOUT_BYTES && M != 8 && M != 16 && M != 32) return false;
+  if (layout == LAYOUT_BITS && (M < 4 || M % 4 != 0)) return false;
+  return qb == 1 && ea == EA_QUEUE && !seq && n_buckets >= 16 && n_buckets <= BF_MAX_BUCKETS &&
+         (n_buckets & (n_buckets - 1)) == 0;
 }
 
 #define VAQ_BF_M(A)                                                                              \
   return p.bucket_shift == 0 ? launch_scan_kernel(scan_bytes_bf_kernel<A, true>, p, lds, grid, st) \
                              : launch_scan_kernel(scan_bytes_bf_kernel<A, false>, p, lds, grid, st);
+#define VAQ_BF_W(A)                                                                                           \
+  if (p.bf_carry)                                                                                             \
+    return p.bucket_shift == 0 ? launch_scan_kernel(scan_bits_bf_kernel<A, true, true>, p, lds, grid, st)      \
+                               : launch_scan_kernel(scan_bits_bf_kernel<A, true, false>, p, lds, grid, st);    \
+  return p.bucket_shift == 0 ? launch_scan_kernel(scan_bits_bf_kernel<A, false, true>, p, lds, grid, st)       \
+                             : launch_scan_kernel(scan_bits_bf_kernel<A, false, false>, p, lds, grid, st);
 
 hipError_t launch_scan_bf(const ScanParams &p, int grid, hipStream_t st) {
   if (!scan_bf_supported(p.layout, p.M, p.qb, p.ea, p.n_buckets, p.seq) || p.ti || p.slice_order)
     return hipErrorInvalidValue;
-  const size_t lds = scan_bf_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.k, p.nwaves, p.n_buckets);
-  switch (p.M) {
-  case 8:  VAQ_BF_M(8)
-  case 16: VAQ_BF_M(16)
-  case 32: VAQ_BF_M(32)
+  if (p.layout == LAYOUT_BITS && (p.lds_subs != p.M || p.lut_lds_entries != p.lut_floats))
+    return hipErrorInvalidValue;  // every table must sit in LDS
+  const size_t lds = scan_bf_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.k, p.nwaves, p.n_buckets, p.bf_carry);
+  if (p.layout == LAYOUT_BYTES) {
+    switch (p.M) {
+    case 8:  VAQ_BF_M(8)
+    case 16: VAQ_BF_M(16)
+    case 32: VAQ_BF_M(32)
+    default: return hipErrorInvalidValue;
+    }
+  }
+  switch (p.W) {
+  case 1: VAQ_BF_W(1)
+  case 2: VAQ_BF_W(2)
+  case 3: VAQ_BF_W(3)
+  case 4: VAQ_BF_W(4)
+  case 5: VAQ_BF_W(5)
+  case 6: VAQ_BF_W(6)
+  case 7: VAQ_BF_W(7)
+  case 8: VAQ_BF_W(8)
   default: return hipErrorInvalidValue;
   }
 }

@@ -125,6 +125,7 @@ struct Plan {
   int64_t seed_rows, seed_stride;
   bool ordered;  // slices dispatched best-first per query batch
   bool bf = false;  // best-first scan form (vaq_scan_bf.h)
+  int bf_carry = 0;
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -243,9 +244,11 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       pl->slice_rows >= 8 * (N / ix->n_buckets + 1)) {
     int bnw = 0, bscore = 0;
     size_t blds = 0;
+    // bit-packed rows: when every field after the first group lies in the last dword, it is queued
+    const int carry = (ix->layout == vaq::LAYOUT_BITS && ix->M > 4 && ix->sub[4].word == ix->W - 1) ? 1 : 0;
     for (int nw : {4, 8, 16}) {
       if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
-      const size_t lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, k, nw, ix->n_buckets);
+      const size_t lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, k, nw, ix->n_buckets, carry);
       if (lds > LDS_LIMIT) continue;
       const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
       // small workgroups win here even at lower residency: setup, bootstrap and the final sort
@@ -256,6 +259,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
     }
     if (bnw) {
       pl->bf = true;
+      pl->bf_carry = carry;
       pl->nwaves = bnw;
       pl->lds = blds;
     }
@@ -406,6 +410,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bucket_t = ix->bucket_t;
     sp.n_hot = 0;
     sp.bf = 0;
+    sp.bf_carry = 0;
     sp.no_skip = ix->opt_no_skip;
     sp.stats = nullptr;
 #ifdef VAQ_STATS
@@ -527,6 +532,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                 (int64_t)sp.n_buckets <= (int64_t)(ix->layout == vaq::LAYOUT_BYTES ? ix->M * 256 : pl.lut_lds_entries) * pl.qb &&
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     sp.bf = pl.bf ? 1 : 0;
+    sp.bf_carry = pl.bf_carry;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
 #ifdef VAQ_STATS
     {
