@@ -11,6 +11,11 @@
 //               [--groundtruth gt.ivecs] [--result out.csv] [--bits 8,8,...]
 //               [--visit-cluster 0.25]     (demo_vaq.cpp:43,57; with a ...,EA_TI<T>m<seg> method)
 //               [--ti-clusters c.f32]      (raw T x seg*L float32; default: random decoded rows)
+//               [--refine 100,200 --dataset-refine base.fvecs [--dataset-size N]]
+//                                          (demo_vaq.cpp:40, :312-345 and scripts/run_demos.sh:9,22: per value R,
+//                                           search R >= k candidates, then VAQ::refine re-ranks them against the
+//                                           raw vectors; results go to <result>_R<R> when several R are given)
+//               [--devices 0,1,2,3]        (shard the rows over these GPUs: RCCL all-gather + merge)
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -65,17 +70,56 @@ int main(int argc, char **argv) {
     const int k = std::atoi(a["k"].c_str());
     std::cout << "index: " << vaq.mCodebook.rows() << " rows x " << M << " subspaces, D=" << D
               << ", queries " << queries.rows() << ", k=" << k << std::endl;
+    if (a.count("devices")) {
+      std::vector<int> devs;
+      std::stringstream ss(a["devices"]);
+      std::string t;
+      while (std::getline(ss, t, ',')) devs.push_back(std::atoi(t.c_str()));
+      vaq.setDevices(devs);
+      std::cout << "sharding the rows over " << devs.size() << " device entr" << (devs.size() == 1 ? "y" : "ies") << std::endl;
+    }
+    // --refine R1,R2,... (demo_vaq.cpp:312-323); without it one plain search (refine = 0)
+    std::vector<int> refines;
+    if (a.count("refine")) {
+      std::stringstream ss(a["refine"]);
+      std::string t;
+      while (std::getline(ss, t, ',')) refines.push_back(std::atoi(t.c_str()));
+    }
+    if (refines.empty()) refines.push_back(0);
+    RowMatrixF datasetrefine;
+    bool any_refine = false;
+    for (const int r : refines) any_refine = any_refine || r >= k;
+    if (any_refine) {
+      if (!a.count("dataset-refine")) throw Error(VAQHIP_EINVAL, "--refine needs --dataset-refine <raw vectors .fvecs>");
+      datasetrefine = readFVecs(a["dataset-refine"], N, a.count("dataset-size") ? std::atoi(a["dataset-size"].c_str()) : -1,
+                                0);
+    }
+    RowMatrix<int> gt;
+    if (a.count("groundtruth")) gt = readIVecs(a["groundtruth"], k);
     vaq.sync();
-    auto t0 = std::chrono::steady_clock::now();
-    LabelDistVecF answers = vaq.search(queries, k, true);
-    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::cout << "== Querying time: " << sec << " s (" << queries.rows() / sec << " queries/s, host buffers in and out)"
-              << std::endl;
-    if (a.count("result")) writeKNNResults(a["result"], answers, queries.rows());
-    if (a.count("groundtruth")) {
-      RowMatrix<int> gt = readIVecs(a["groundtruth"], k);
-      std::cout << "recall@" << k << ": " << getAvgRecall(answers.labels, gt, k)
-                << "  recall@R: " << getRecallAtR(answers.labels, gt, k) << std::endl;
+    for (const int refine : refines) {
+      auto t0 = std::chrono::steady_clock::now();
+      const int searchK = refine >= k ? refine : k;  // demo_vaq.cpp:338
+      LabelDistVecF answers = vaq.search(queries, searchK, true);
+      if (refine >= k) {
+        std::cout << "Refining the answer with Refine = " << refine << std::endl;
+        // the raw queries (first N dims), as the reference passes them (demo_vaq.cpp:342)
+        RowMatrixF qraw((size_t)queries.rows(), (size_t)N);
+        for (size_t i = 0; i < qraw.rows(); i++)
+          for (size_t j = 0; j < qraw.cols(); j++) qraw(i, j) = queries(i, j);
+        answers = vaq.refine(qraw, answers, datasetrefine, k);
+      }
+      double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::cout << "== Querying time: " << sec << " s (" << queries.rows() / sec
+                << " queries/s, host buffers in and out)" << std::endl;
+      if (a.count("result")) {
+        std::string fp = a["result"];
+        if (refines.size() > 1) fp += "_R" + std::to_string(refine);  // demo_vaq.cpp:349-351
+        writeKNNResults(fp, answers, queries.rows());
+      }
+      if (a.count("groundtruth"))
+        std::cout << "\tprecision(avg_recall): " << getAvgRecall(answers.labels, gt, k)
+                  << "\n\trecall@R: " << getRecallAtR(answers.labels, gt, k) << std::endl;
     }
   } catch (const std::exception &e) {
     std::cerr << "error: " << e.what() << std::endl;

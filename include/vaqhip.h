@@ -20,8 +20,12 @@
  *    hipStream_t (passed as void*), enqueue only, and never synchronise
  *  - the library has no CPU fallback: without a usable HIP device every call
  *    fails with VAQHIP_ENODEVICE
- *  - one index may be used from several host threads; calls on the same
- *    index are serialised internally
+ *  - one index may be used from several host threads and several streams: calls on the same
+ *    index are serialised internally on the host, and since every call shares the index's
+ *    workspaces (lookup tables, partial lists, thresholds), a "_device" call on a stream other
+ *    than the one the previous call used makes its stream wait (hipStreamWaitEvent) for that
+ *    call's work first -- searches on one index never overlap on the GPU; use one index per
+ *    stream (or vaqhip_multi) for concurrency
  */
 #ifndef VAQHIP_H_
 #define VAQHIP_H_
@@ -203,6 +207,54 @@ int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
                                      const int32_t *d_label_lists, int n_lists,
                                      int64_t list_stride, int64_t query_stride, int nq, int k,
                                      int32_t *d_labels_out, float *d_dist_out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Multi-device index (north_star: "the code database shards
+ * naturally across the 8 GPUs of one node with a final RCCL all-gather of per-shard top-k").
+ * One process, one host thread per GPU.  set_codes cuts the rows into contiguous shards (shard g =
+ * rows [g * ceil(N/G), (g+1) * ceil(N/G)), labels stay global row numbers); every device answers
+ * all queries on its shard; the exchange step is ONE ncclAllGather (RCCL over xGMI) of the packed
+ * per-shard results followed by the k-min merge by (distance, label): the result equals a single
+ * index over all rows bit for bit.  The reference's precedent for shard-and-merge is
+ * BitVecEngine.cpp:1034-1132 (merge at :1114-1126); its own search is single-threaded on one host
+ * (VAQ.cpp:776-847), so this is the form `class VAQ` takes on a multi-GPU node.
+ *   device_ids   HIP ordinals, one per shard.  Naming one GPU several times gives LOGICAL shards
+ *                on that GPU (RCCL refuses duplicate devices, so the gather is then done with
+ *                device-to-device copies; same buffers, same merge) -- how a one-GPU box tests
+ *                the sharded path.
+ * Options ("exchange": 0 auto, 1 RCCL, 2 copies; anything else is forwarded to every shard).
+ * ------------------------------------------------------------------------- */
+#define VAQHIP_MAX_DEVICES 16
+typedef struct vaqhip_multi vaqhip_multi;
+int vaqhip_multi_create(vaqhip_multi **out, int D, int M, const int *bits,
+                        const float *const *centroids_rowmajor, const float *eigvec_real_rowmajor,
+                        int n_devices, const int *device_ids, unsigned flags);
+void vaqhip_multi_destroy(vaqhip_multi *mx);
+/* mCodebook for the whole database (host pointer); sharded contiguously across the devices */
+int vaqhip_multi_set_codes_u16(vaqhip_multi *mx, const uint16_t *codes_rowmajor, int64_t N, int64_t id_base);
+/* append: the new rows continue the numbering, so they extend the last shard */
+int vaqhip_multi_add_codes_u16(vaqhip_multi *mx, const uint16_t *codes_rowmajor, int64_t n_new);
+/* VAQ::search on every shard + exchange + merge; host pointers, synchronous */
+int vaqhip_multi_search(vaqhip_multi *mx, const float *queries_rowmajor, int nq, int k, int projected,
+                        int32_t *labels, float *distances);
+/* forwarded to every shard (each shard regroups its own rows under the same TI centres) */
+int vaqhip_multi_set_ti_clusters(vaqhip_multi *mx, const float *clusters_rowmajor, int T, int seg_num);
+int vaqhip_multi_set_method(vaqhip_multi *mx, unsigned methods, float visit);
+int vaqhip_multi_set_option(vaqhip_multi *mx, const char *key, int64_t value);
+typedef struct {
+  int n_devices;
+  int exchange;              /* what the last search used: 0 none (one shard), 1 RCCL all-gather, 2 copies */
+  int64_t N, id_base;
+  int device_ids[VAQHIP_MAX_DEVICES];
+  int64_t shard_rows[VAQHIP_MAX_DEVICES];
+  float last_search_ms;      /* device time on shard 0: upload + project + LUT + scan (+ merge of its slices) */
+  float last_exchange_ms;    /*   the all-gather (or the copies), incl. waiting for the slowest shard       */
+  float last_merge_ms;       /*   the G-way merge kernel                                                     */
+} vaqhip_multi_info;
+int vaqhip_multi_get_info(const vaqhip_multi *mx, vaqhip_multi_info *out);
+/* shard g's single-device index (options, timing, info); owned by the multi index */
+vaqhip_index *vaqhip_multi_shard(vaqhip_multi *mx, int g);
+const char *vaqhip_multi_last_error(void);
 
 /* ----- introspection / tuning -------------------------------------------- */
 typedef struct {

@@ -83,11 +83,23 @@ public:
   RowMatrixF mTIClusters;
   int64_t mIdBase = 0;                        // shard offset (not in the reference: single node)
   int mDevice = 0;
+  // Several GPUs of the node (not in the reference, which is one host thread on one CPU): with
+  // setDevices({0, 1, ..}) the code rows are sharded contiguously over them and search() ends
+  // with the RCCL all-gather + merge of vaqhip_multi_search; results are unchanged.
+  std::vector<int> mDevices;
+  void setDevices(const std::vector<int> &devices) {
+    invalidate();
+    mDevices = devices;
+    if (!devices.empty()) mDevice = devices[0];
+  }
 
   VaqHip() = default;
   VaqHip(const VaqHip &) = delete;
   VaqHip &operator=(const VaqHip &) = delete;
-  ~VaqHip() { vaqhip_index_destroy(h_); }
+  ~VaqHip() {
+    vaqhip_index_destroy(h_);
+    vaqhip_multi_destroy(mh_);
+  }
 
   int mHighestSubs() const { return (int)mBitsAlloc.size(); }
   int mSubsLen() const { return mCentroidsPerSubs.empty() ? 0 : (int)mCentroidsPerSubs[0].cols(); }
@@ -143,6 +155,10 @@ public:
   void sync() {
     const int M = mHighestSubs();
     if (M == 0 || (int)mCentroidsPerSubs.size() != M) throw Error(VAQHIP_EINVAL, "vaqhip: state not set");
+    if (!mDevices.empty()) {
+      syncMulti();
+      return;
+    }
     if (!h_) {
       std::vector<const float *> cp(M);
       for (int s = 0; s < M; s++) {
@@ -173,8 +189,44 @@ public:
       codes_set_ = true;
     }
   }
+  // the same for the multi-device index (mDevices set)
+  void syncMulti() {
+    const int M = mHighestSubs();
+    if (!mh_) {
+      std::vector<const float *> cp(M);
+      for (int s = 0; s < M; s++) {
+        if ((int)mCentroidsPerSubs[s].rows() != (1 << mBitsAlloc[s]))
+          throw Error(VAQHIP_EINVAL, "vaqhip: centroid rows != 1 << bits");
+        cp[s] = mCentroidsPerSubs[s].data();
+      }
+      checkMulti(vaqhip_multi_create(&mh_, mTotalDim(), M, mBitsAlloc.data(), cp.data(),
+                                     mEigenVectors.rows() ? mEigenVectors.data() : nullptr, (int)mDevices.size(),
+                                     mDevices.data(), 0u));
+      codes_set_ = false;
+      ti_set_ = false;
+    }
+    if ((mMethods & NNMethod::TI) && !ti_set_) {
+      const int seg = mTISegmentNum == -1 ? M : mTISegmentNum;
+      if (mTIClusters.rows() == 0 || (int)mTIClusters.cols() != seg * mSubsLen())
+        throw Error(VAQHIP_ESTATE, "vaqhip: method TI needs mTIClusters (T x seg*L); see clusterTI()");
+      checkMulti(vaqhip_multi_set_ti_clusters(mh_, mTIClusters.data(), (int)mTIClusters.rows(), seg));
+      ti_set_ = true;
+    } else if (!(mMethods & NNMethod::TI) && ti_set_) {
+      checkMulti(vaqhip_multi_set_ti_clusters(mh_, nullptr, 0, 0));
+      ti_set_ = false;
+    }
+    checkMulti(vaqhip_multi_set_method(mh_, mMethods, mVisit));
+    if (!codes_set_) {
+      if (mCodebook.cols() != (size_t)M && mCodebook.rows() != 0)
+        throw Error(VAQHIP_EINVAL, "vaqhip: mCodebook is not N x M");
+      checkMulti(vaqhip_multi_set_codes_u16(mh_, mCodebook.data(), (int64_t)mCodebook.rows(), mIdBase));
+      codes_set_ = true;
+    }
+  }
   // call after changing any public member
   void invalidate() {
+    vaqhip_multi_destroy(mh_);
+    mh_ = nullptr;
     vaqhip_index_destroy(h_);
     h_ = nullptr;
     codes_set_ = false;
@@ -218,7 +270,10 @@ public:
     ret.labels.resize(k * nq);
     ret.distances.resize(k * nq);
     if ((int)XTest.cols() != mTotalDim()) throw Error(VAQHIP_EINVAL, "vaqhip: XTest has the wrong width");
-    check(vaqhip_search(h_, XTest.data(), (int)nq, k, ret.labels.data(), ret.distances.data()));
+    if (mh_)
+      checkMulti(vaqhip_multi_search(mh_, XTest.data(), (int)nq, k, 0, ret.labels.data(), ret.distances.data()));
+    else
+      check(vaqhip_search(h_, XTest.data(), (int)nq, k, ret.labels.data(), ret.distances.data()));
     return ret;
   }
 
@@ -231,7 +286,8 @@ public:
     try { sync(); } catch (...) { codes_set_ = had; throw; }
     codes_set_ = false;
     mCodebook = CodebookType((size_t)XTrain.rows(), (size_t)mHighestSubs());
-    check(vaqhip_encode(h_, XTrain.data(), (int64_t)XTrain.rows(), projected ? 1 : 0, mCodebook.data()));
+    vaqhip_index *enc = mh_ ? vaqhip_multi_shard(mh_, 0) : h_;  // (every shard holds the codebooks)
+    check(vaqhip_encode(enc, XTrain.data(), (int64_t)XTrain.rows(), projected ? 1 : 0, mCodebook.data()));
   }
 
   // VAQ::refine, VAQ.hpp:104 / VAQ.cpp:849-876
@@ -269,14 +325,47 @@ public:
     for (size_t i = 0; i < D; i++)
       for (size_t j = 0; j < mEigenVectors.cols(); j++) mEigenVectors(i, j) = v.mEigenVectors(i, j).real();
     mCodebook = CodebookType(v.mCodebook.rows(), v.mCodebook.cols());
-    for (size_t i = 0; i < mCodebook.rows(); i++)
-      for (size_t j = 0; j < mCodebook.cols(); j++) mCodebook(i, j) = v.mCodebook(i, j);
+    // VAQ::clusterTI ends by REGROUPING mCodebook (VAQ.cpp:984-996: row r of the grouped matrix
+    // is original row mTIClustersMember[c][r - start_c]) while search() keeps returning ORIGINAL
+    // row numbers (VAQ.cpp:1575-1590).  This index regroups its own copy and labels by position
+    // in the matrix it is given, so a codebook that was already regrouped is put back into
+    // original order first; before clusterTI (no members yet) it is copied as it is.
+    size_t members = 0;
+    for (const auto &cm : v.mTIClustersMember) members += cm.size();
+    if (members == 0) {
+      for (size_t i = 0; i < mCodebook.rows(); i++)
+        for (size_t j = 0; j < mCodebook.cols(); j++) mCodebook(i, j) = v.mCodebook(i, j);
+    } else {
+      if (members != mCodebook.rows())
+        throw Error(VAQHIP_ESTATE, "vaqhip: mTIClustersMember does not cover mCodebook");
+      size_t r = 0;
+      for (const auto &cm : v.mTIClustersMember)
+        for (const int idx : cm) {
+          for (size_t j = 0; j < mCodebook.cols(); j++) mCodebook((size_t)idx, j) = v.mCodebook(r, j);
+          r++;
+        }
+    }
+    // the TI state search() reads (VAQ.hpp:77-84)
+    mTIClusterNum = v.mTIClusterNum;
+    mTISegmentNum = v.mTISegmentNum;
+    mVisit = v.mVisit;
+    mTIClusters = RowMatrixF((size_t)v.mTIClusters.rows(), (size_t)v.mTIClusters.cols());
+    for (size_t i = 0; i < mTIClusters.rows(); i++)
+      for (size_t j = 0; j < mTIClusters.cols(); j++) mTIClusters(i, j) = v.mTIClusters(i, j);
+    if ((mMethods & NNMethod::TI) && mTIClusters.rows() == 0)
+      throw Error(VAQHIP_ESTATE, "vaqhip: the reference object selects TI but has no mTIClusters yet "
+                                 "(call its clusterTI() first, or clusterTI() here)");
   }
 
   vaqhip_index *handle() { return h_; }
+  vaqhip_multi *multiHandle() { return mh_; }
 
 private:
+  static void checkMulti(int rc) {
+    if (rc < 0) throw Error(rc, std::string("vaqhip: ") + vaqhip_multi_last_error());
+  }
   vaqhip_index *h_ = nullptr;
+  vaqhip_multi *mh_ = nullptr;
   bool codes_set_ = false;
   bool ti_set_ = false;
 };

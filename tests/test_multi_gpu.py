@@ -1,0 +1,92 @@
+"""The multi-device index of the C ABI (vaqhip_multi_*) on ONE GPU: logical shards on device 0
+exercise the sharding, the exchange step (device copies, and RCCL itself with one rank) and the
+merge; the result must equal the single index bit for bit.  Real multi-GPU runs are the
+driver's; the per-rank form of the same path is tests/test_sharding_gloo.py."""
+import numpy as np
+import pytest
+
+from helpers import assert_topk_matches, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def single(c):
+    import vaq_amd
+    v = vaq_amd.VaqHip()
+    v.mBitsAlloc = list(c["bits"])
+    v.mCentroidsPerSubs = c["cents"]
+    v.mEigenVectors = c["eig"]
+    v.mCodebook = c["codes"]
+    return v
+
+
+@pytest.mark.parametrize("bits,N", [([8] * 8, 300_000), ([12, 10, 9, 8, 8, 7, 6, 4], 100_000), ([8] * 16, 5)],
+                         ids=["m8", "nonuniform", "fewer_rows_than_shards"])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0, 0, 0, 0]], ids=["1", "2", "8"])
+def test_logical_shards_equal_single_index(vaqlib, oracle, bits, N, devices):
+    from vaq_amd.index import VaqHipMulti
+    c = make_case(4100 + len(devices), 128, bits, N, 19, dup_frac=0.02)
+    k = 100
+    ref = single(c).search(c["X"], k)
+    m = VaqHipMulti(devices, c["bits"], c["cents"], c["eig"])
+    m.set_codes(c["codes"])
+    inf = m.info()
+    per = (N + len(devices) - 1) // len(devices)
+    assert inf["shard_rows"] == [max(0, min(N, (g + 1) * per) - min(N, g * per)) for g in range(len(devices))]
+    for qb in (0, 1, 2):
+        m.set_option("queries_per_pass", qb)
+        a = m.search(c["X"], k)
+        assert np.array_equal(a.labels, ref.labels) and np.array_equal(a.distances.view(np.uint32), ref.distances.view(np.uint32))
+    inf = m.info()
+    assert inf["exchange"] == (0 if len(devices) == 1 else 2)  # none / device copies (RCCL refuses duplicate GPUs)
+    # against the oracle too (the single index is itself checked elsewhere)
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
+    ad = np.stack([oracle.all_dists(oracle.create_lut(Xp[q], c["cents"], max(bits)), c["codes"]) for q in range(19)])
+    assert_topk_matches(a.labels.reshape(19, k), a.distances.reshape(19, k), o_lab, o_dis, ad, what="multi")
+    m.close()
+
+
+def test_rccl_binding_one_rank(vaqlib):
+    """exchange = 1 runs ncclCommInitAll + ncclAllGather (one rank: a copy) on the GPU that is
+    there: the RCCL binding of the C++ host is exercised end to end."""
+    from vaq_amd.index import VaqHipMulti
+    c = make_case(4200, 128, [8] * 8, 50_000, 7)
+    ref = single(c).search(c["X"], 10)
+    m = VaqHipMulti([0], c["bits"], c["cents"], c["eig"])
+    m.set_codes(c["codes"])
+    m.set_option("exchange", 1)
+    a = m.search(c["X"], 10)
+    assert m.info()["exchange"] == 1
+    assert np.array_equal(a.labels, ref.labels) and np.array_equal(a.distances, ref.distances)
+    import vaq_amd
+    m2 = VaqHipMulti([0, 0], c["bits"], c["cents"], c["eig"])
+    with pytest.raises(vaq_amd.VaqHipError):
+        m2.set_option("exchange", 1)  # RCCL needs distinct devices
+    m.close()
+    m2.close()
+
+
+def test_multi_append_ti_and_errors(vaqlib, oracle):
+    from vaq_amd.index import VaqHipMulti
+    import vaq_amd
+    c = make_case(4300, 64, [8] * 8, 40_000, 9)
+    m = VaqHipMulti([0, 0, 0], c["bits"], c["cents"], c["eig"])
+    m.set_codes(c["codes"][:30_000])
+    m.add_codes(c["codes"][30_000:])  # extends the last shard; labels continue
+    assert m.info()["N"] == 40_000 and sum(m.info()["shard_rows"]) == 40_000
+    ref = single(c).search(c["X"], 50)
+    a = m.search(c["X"], 50)
+    assert np.array_equal(a.labels, ref.labels) and np.array_equal(a.distances, ref.distances)
+    # TI: every shard regroups its own rows under the same centres; visit = 1 and EA give the exact top-k
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 40_000, size=20)
+    cl = np.concatenate([c["cents"][s][c["codes"][pick, s].astype(np.int64)] for s in range(4)], axis=1)
+    m.set_ti_clusters(cl, 4)
+    m.set_method(vaq_amd.NNMethod.TI | vaq_amd.NNMethod.EA, 1.0)
+    t = m.search(c["X"], 50)
+    assert np.array_equal(np.sort(t.labels.reshape(9, 50), 1), np.sort(ref.labels.reshape(9, 50), 1))
+    assert np.allclose(t.distances, np.sqrt(ref.distances), rtol=1e-6)
+    with pytest.raises(vaq_amd.VaqHipError):
+        VaqHipMulti([], c["bits"], c["cents"], c["eig"])
+    m.close()

@@ -264,7 +264,39 @@ def test_cpp_demo_driver(vaqlib, oracle, tmp_path):
     # distances are not in the CSV: check labels under the tie contract via their oracle distances
     d_got = np.take_along_axis(ad, got, axis=1).astype(np.float32)
     assert_topk_matches(got.astype(np.int32), d_got, o_lab, o_dis, ad, what="cpp demo")
-    assert "recall@100: 1" in r.stdout
+    assert "precision(avg_recall): 1" in r.stdout
+
+
+def test_cpp_demo_driver_refine_and_devices(vaqlib, oracle, tmp_path):
+    """The rest of demo_vaq's query surface (demo_vaq.cpp:312-361, scripts/run_demos.sh "--refine
+    100,200"): per R, search R candidates then VAQ::refine against the raw vectors -- here with
+    the rows sharded over two logical devices (setDevices -> vaqhip_multi_search)."""
+    import subprocess
+    from vaq_amd import build, io
+    exe = build.build_demo()
+    c = make_case(611, 128, [8] * 8, 20000, 12)
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, size=(20000, 128)).astype(np.float32)  # the raw vectors refine() reads
+    io.save_centroids(c["cents"], str(tmp_path / "c.bin"))
+    io.save_codebook(c["codes"], str(tmp_path / "cb.bin"))
+    c["eig"].astype(np.float32).tofile(str(tmp_path / "e.f32"))
+    io.write_vecs(str(tmp_path / "q.fvecs"), c["X"])
+    io.write_vecs(str(tmp_path / "base.fvecs"), base)
+    r = subprocess.run([exe, "--centroids", str(tmp_path / "c.bin"), "--codebook", str(tmp_path / "cb.bin"),
+                        "--eigen", str(tmp_path / "e.f32"), "--queries", str(tmp_path / "q.fvecs"),
+                        "--timeseries-size", "128", "--k", "100", "--method", "VAQ64m8min8max8var1,HEAP",
+                        "--refine", "100,200", "--dataset-refine", str(tmp_path / "base.fvecs"),
+                        "--devices", "0,0", "--result", str(tmp_path / "out.csv")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Refining the answer with Refine = 200" in r.stdout and "sharding the rows over 2" in r.stdout
+    for R in (100, 200):
+        got = np.loadtxt(str(tmp_path / f"out.csv_R{R}"), delimiter=",", dtype=np.int64)
+        cand, _ = oracle.search(c["X"], c["cents"], c["codes"], R, eig=c["eig"])
+        o_lab, o_dis = oracle.refine(c["X"], base, cand, 100)
+        d_got = ((c["X"][:, None, :] - base[got]) ** 2).sum(-1).astype(np.float32)
+        assert np.array_equal(np.sort(got, 1), np.sort(o_lab, 1)), R
+        assert np.allclose(d_got, o_dis, rtol=1e-6), R
 
 
 @pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[4], CONFIGS[5], CONFIGS[6], CONFIGS[10]],
@@ -525,3 +557,61 @@ def test_best_first_rounds_multislice(vaqlib, oracle, bits):
             ran += v.last_timing()["best_first"]
         v.close()
     assert ran >= 4, ran
+
+
+def test_two_streams_two_threads_one_index(vaqlib, oracle):
+    """The index's workspaces are shared by every call: `_device` searches issued by two host
+    threads on two different streams must not overwrite each other's lookup tables / partial
+    lists (the library orders them with an event), and a host-buffer search in between must
+    not either."""
+    import threading
+    import torch
+    c = make_case(8801, 128, [8] * 8, 200_000, 64, dup_frac=0.01)
+    v = make_index(c)
+    k = 50
+    X = torch.from_numpy(c["X"]).cuda()
+    halves = [X[:32].contiguous(), X[32:].contiguous()]
+    ref = [v.search(c["X"][:32], k), v.search(c["X"][32:], k)]
+    errors = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(40):
+                    l, d = v.search_device(halves[i], k)
+                    if rep % 8 == 0:  # a host-buffer call on the index's own stream in between
+                        h = v.search(c["X"][i * 32:(i + 1) * 32], k)
+                        assert np.array_equal(h.labels, ref[i].labels)
+                    st.synchronize()
+                    assert np.array_equal(l.cpu().numpy().ravel(), ref[i].labels), (i, rep)
+                    assert np.array_equal(d.cpu().numpy().ravel(), ref[i].distances), (i, rep)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    # encode from two threads while searching (vaqhip_encode holds the index lock throughout)
+    Xp = oracle.project(c["X"], c["eig"])
+    o_codes = oracle.encode(Xp, c["cents"])
+
+    def enc():
+        try:
+            for _ in range(10):
+                import vaq_amd
+                w = np.empty((64, 8), np.uint16)
+                vaq_amd._lib.check(vaqlib.vaqhip_encode(v._h, Xp.ctypes.data, 64, 1, w.ctypes.data))
+                assert np.array_equal(w, o_codes)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=enc), threading.Thread(target=work, args=(0,))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors

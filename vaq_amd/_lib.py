@@ -22,7 +22,11 @@ SYMBOLS = [
     "vaqhip_encode", "vaqhip_encode_device", "vaqhip_refine", "vaqhip_refine_device",
     "vaqhip_index_info", "vaqhip_set_option", "vaqhip_last_timing", "vaqhip_last_error",
     "vaqhip_version", "vaqhip_device_count",
+    "vaqhip_multi_create", "vaqhip_multi_destroy", "vaqhip_multi_set_codes_u16", "vaqhip_multi_add_codes_u16",
+    "vaqhip_multi_search", "vaqhip_multi_set_ti_clusters", "vaqhip_multi_set_method", "vaqhip_multi_set_option",
+    "vaqhip_multi_get_info", "vaqhip_multi_shard", "vaqhip_multi_last_error",
 ]
+MAX_DEVICES = 16
 
 ERROR_NAMES = {
     -1: "EINVAL", -2: "EUNSUPPORTED", -3: "ENODEVICE", -4: "ENOMEM", -5: "EHIP",
@@ -51,6 +55,12 @@ class Timing(C.Structure):
                 ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int),
                 ("seed_slices", C.c_int), ("early_abandon", C.c_int),
                 ("best_first", C.c_int)]
+
+
+class MultiInfo(C.Structure):
+    _fields_ = [("n_devices", C.c_int), ("exchange", C.c_int), ("N", C.c_int64), ("id_base", C.c_int64),
+                ("device_ids", C.c_int * 16), ("shard_rows", C.c_int64 * 16), ("last_search_ms", C.c_float),
+                ("last_exchange_ms", C.c_float), ("last_merge_ms", C.c_float)]
 
 
 _lib = None
@@ -108,6 +118,20 @@ def load():
     L.vaqhip_set_option.argtypes = [vp, C.c_char_p, i64]
     L.vaqhip_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.vaqhip_last_error.restype = C.c_char_p
+    L.vaqhip_multi_create.argtypes = [C.POINTER(vp), i32, i32, C.POINTER(i32), C.POINTER(C.POINTER(C.c_float)), vp,
+                                      i32, C.POINTER(i32), C.c_uint]
+    L.vaqhip_multi_destroy.argtypes = [vp]
+    L.vaqhip_multi_destroy.restype = None
+    L.vaqhip_multi_set_codes_u16.argtypes = [vp, vp, i64, i64]
+    L.vaqhip_multi_add_codes_u16.argtypes = [vp, vp, i64]
+    L.vaqhip_multi_search.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.vaqhip_multi_set_ti_clusters.argtypes = [vp, vp, i32, i32]
+    L.vaqhip_multi_set_method.argtypes = [vp, C.c_uint, C.c_float]
+    L.vaqhip_multi_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.vaqhip_multi_get_info.argtypes = [vp, C.POINTER(MultiInfo)]
+    L.vaqhip_multi_shard.argtypes = [vp, i32]
+    L.vaqhip_multi_shard.restype = vp
+    L.vaqhip_multi_last_error.restype = C.c_char_p
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int:
@@ -119,5 +143,12 @@ def load():
 def check(rc: int) -> int:
     if rc < 0:
         msg = load().vaqhip_last_error()
+        raise VaqHipError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def check_multi(rc: int) -> int:
+    if rc < 0:
+        msg = load().vaqhip_multi_last_error()
         raise VaqHipError(rc, msg.decode() if msg else "")
     return rc

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vaq_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "vaq_amd", "lib")
 LIB = os.path.join(LIBDIR, "libvaqhip.so")
-SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_ti.hip", "vaqhip_api.cpp"]
+SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_ti.hip", "vaqhip_api.cpp", "vaqhip_multi.cpp"]
 KERNEL_HEADER = os.path.join(CSRC, "vaq_kernels.h")
 API_HEADER = os.path.join(ROOT, "include", "vaqhip.h")
 
@@ -95,7 +95,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             f.write(_flags_tag())
     objs = [_obj(s) for s in SOURCES]
     if todo or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -90,6 +90,13 @@ struct vaqhip_index {
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
   hipStream_t stream = nullptr;
+  // The workspaces above are shared by every call on this index.  Host-side enqueues are
+  // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
+  // that used the workspaces leaves an event, and a call on a DIFFERENT stream makes its stream
+  // wait for it first (same stream: in order anyway).
+  hipEvent_t ws_event = nullptr;
+  hipStream_t ws_stream = nullptr;
+  bool ws_used = false;
   // options
   int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1;
   // timing: a ring of 5-event sets, one per search since the last read
@@ -322,6 +329,19 @@ int make_ti_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   return VAQHIP_OK;
 }
 
+// before / after enqueueing work that touches the index's shared workspaces on stream `st`
+int ws_acquire(vaqhip_index *ix, hipStream_t st) {
+  if (!ix->ws_event) HIP_TRY(hipEventCreateWithFlags(&ix->ws_event, hipEventDisableTiming));
+  if (ix->ws_used && st != ix->ws_stream) HIP_TRY(hipStreamWaitEvent(st, ix->ws_event, 0));
+  return VAQHIP_OK;
+}
+int ws_release(vaqhip_index *ix, hipStream_t st) {
+  HIP_TRY(hipEventRecord(ix->ws_event, st));
+  ix->ws_stream = st;
+  ix->ws_used = true;
+  return VAQHIP_OK;
+}
+
 int ensure_events(vaqhip_index *ix) {
   if (!ix->ev.empty()) return VAQHIP_OK;
   std::vector<hipEvent_t> ev(vaqhip_index::EV_SETS * 6);
@@ -342,6 +362,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   if (nq == 0) return VAQHIP_OK;
   if (!d_queries || !d_labels || !d_dist) return fail(VAQHIP_EINVAL, "null pointer");
 
+  {
+    int rc = ws_acquire(ix, st);
+    if (rc) return rc;
+  }
   bool timing = ix->opt_timing != 0;
   hipEvent_t *ev = nullptr;
   if (timing) {
@@ -570,7 +594,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   tm.n_searches = 0;
   ix->last = tm;
   if (timing) ix->ev_used++;
-  return VAQHIP_OK;
+  return ws_release(ix, st);
 }
 
 } // namespace
@@ -706,6 +730,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
       (void)hipStreamDestroy(ix->stream);
     }
     for (auto &e : ix->ev) (void)hipEventDestroy(e);
+    if (ix->ws_event) (void)hipEventDestroy(ix->ws_event);
     for (DevBuf *b : {&ix->d_cent, &ix->d_cent_t, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
                       &ix->d_bstart, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_part_cnt, &ix->w_labels,
@@ -876,6 +901,10 @@ static int search_host(vaqhip_index *ix, const float *queries, int nq, int k, in
   HIP_TRY(ix->w_q.ensure(qbytes));
   HIP_TRY(ix->w_labels.ensure(rbytes));
   HIP_TRY(ix->w_dist.ensure(rbytes));
+  {
+    int rc = ws_acquire(ix, ix->stream);
+    if (rc) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, qbytes, hipMemcpyHostToDevice, ix->stream));
   int rc = search_device_locked(ix, ix->w_q.as<float>(), nq, k, projected, ix->w_labels.as<int32_t>(),
                                 ix->w_dist.as<float>(), ix->stream);
@@ -910,6 +939,10 @@ int vaqhip_project(vaqhip_index *ix, const float *X, int64_t n, float *out) {
   const int64_t chunk = std::min<int64_t>(n, 1 << 20);
   HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
   HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  {
+    int rc = ws_acquire(ix, ix->stream);
+    if (rc) return rc;
+  }
   for (int64_t r = 0; r < n; r += chunk) {
     const int64_t m = std::min(chunk, n - r);
     const size_t bytes = (size_t)m * ix->D * sizeof(float);
@@ -937,6 +970,10 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int project
   HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
   HIP_TRY(ix->w_lutref.ensure((size_t)chunk * per_q * sizeof(float)));
   hipStream_t st = ix->stream;
+  {
+    int rc = ws_acquire(ix, st);
+    if (rc) return rc;
+  }
   for (int q0 = 0; q0 < nq; q0 += chunk) {
     const int n = std::min(chunk, nq - q0);
     HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries + (size_t)q0 * ix->D, (size_t)n * ix->D * sizeof(float),
@@ -983,18 +1020,16 @@ int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
   return VAQHIP_OK;
 }
 
-int vaqhip_encode_device(vaqhip_index *ix, const float *d_X, int64_t n, int projected,
-                         uint16_t *d_codes, void *stream) {
-  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
-  if (n < 0 || (n > 0 && (!d_X || !d_codes))) return fail(VAQHIP_EINVAL, "bad arguments");
-  if (n == 0) return VAQHIP_OK;
-  std::lock_guard<std::mutex> lk(ix->mu);
-  DeviceGuard g(ix->device);
-  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+// core of vaqhip_encode*: caller holds ix->mu and has the device current
+static int encode_device_locked(vaqhip_index *ix, const float *d_X, int64_t n, int projected, uint16_t *d_codes,
+                                hipStream_t st) {
   const bool do_project = !projected && ix->has_eig;
   const int64_t chunk = std::min<int64_t>(n, 1 << 20);
   if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
+  {
+    int rc = ws_acquire(ix, st);
+    if (rc) return rc;
+  }
   for (int64_t r = 0; r < n; r += chunk) {
     const int64_t m = std::min(chunk, n - r);
     const float *xp = d_X + r * ix->D;
@@ -1005,7 +1040,18 @@ int vaqhip_encode_device(vaqhip_index *ix, const float *d_X, int64_t n, int proj
     HIP_TRY(vaq::launch_encode(xp, m, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
                                ix->d_cent.as<float>(), d_codes + r * ix->M, st));
   }
-  return VAQHIP_OK;
+  return ws_release(ix, st);
+}
+
+int vaqhip_encode_device(vaqhip_index *ix, const float *d_X, int64_t n, int projected,
+                         uint16_t *d_codes, void *stream) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (n < 0 || (n > 0 && (!d_X || !d_codes))) return fail(VAQHIP_EINVAL, "bad arguments");
+  if (n == 0) return VAQHIP_OK;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  return encode_device_locked(ix, d_X, n, projected, d_codes, static_cast<hipStream_t>(stream));
 }
 
 int vaqhip_encode(vaqhip_index *ix, const float *X, int64_t n, int projected, uint16_t *codes) {
@@ -1013,24 +1059,23 @@ int vaqhip_encode(vaqhip_index *ix, const float *X, int64_t n, int projected, ui
   if (n < 0 || (n > 0 && (!X || !codes))) return fail(VAQHIP_EINVAL, "bad arguments");
   if (n == 0) return VAQHIP_OK;
   const int64_t chunk = std::min<int64_t>(n, 1 << 20);
-  {
-    std::lock_guard<std::mutex> lk(ix->mu);
-    DeviceGuard g(ix->device);
-    if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
-    HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
-    HIP_TRY(ix->w_stage.ensure((size_t)chunk * ix->M * sizeof(uint16_t)));
-  }
+  // the staging buffers (w_q, w_stage) are the index's: hold its lock across upload, encode and
+  // download, as search_host does
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  HIP_TRY(ix->w_q.ensure((size_t)chunk * ix->D * sizeof(float)));
+  HIP_TRY(ix->w_stage.ensure((size_t)chunk * ix->M * sizeof(uint16_t)));
   for (int64_t r = 0; r < n; r += chunk) {
     const int64_t m = std::min(chunk, n - r);
     {
-      DeviceGuard g(ix->device);
-      HIP_TRY(hipMemcpyAsync(ix->w_q.p, X + r * ix->D, (size_t)m * ix->D * sizeof(float),
-                             hipMemcpyHostToDevice, ix->stream));
+      int rc = ws_acquire(ix, ix->stream);  // (w_q may still be read by a search on another stream)
+      if (rc) return rc;
     }
-    int rc = vaqhip_encode_device(ix, ix->w_q.as<float>(), m, projected, ix->w_stage.as<uint16_t>(),
-                                  ix->stream);
+    HIP_TRY(hipMemcpyAsync(ix->w_q.p, X + r * ix->D, (size_t)m * ix->D * sizeof(float), hipMemcpyHostToDevice,
+                           ix->stream));
+    int rc = encode_device_locked(ix, ix->w_q.as<float>(), m, projected, ix->w_stage.as<uint16_t>(), ix->stream);
     if (rc) return rc;
-    DeviceGuard g(ix->device);
     HIP_TRY(hipMemcpyAsync(codes + r * ix->M, ix->w_stage.p, (size_t)m * ix->M * sizeof(uint16_t),
                            hipMemcpyDeviceToHost, ix->stream));
     HIP_TRY(hipStreamSynchronize(ix->stream));

@@ -487,3 +487,77 @@ def merge_topk_packed_device(packed, world: int, nq: int, k: int, out=None):
         dev, C.c_void_p(base + nq * k * 4), C.c_void_p(base), world, 2 * nq * k, k, nq, k,
         C.c_void_p(out_l.data_ptr()), C.c_void_p(out_d.data_ptr()), C.c_void_p(st)))
     return out_l, out_d
+
+
+class VaqHipMulti:
+    """One process, several GPUs (include/vaqhip.h "multi-device"): the rows are sharded
+    contiguously over `devices`, every device answers all queries on its shard, one RCCL
+    all-gather + merge finishes the search.  Naming a device several times gives logical shards
+    on that GPU (gather by device copies) -- the form a one-GPU box can test."""
+
+    def __init__(self, devices: Sequence[int], bits: Sequence[int], cents: Sequence[np.ndarray],
+                 eig: Optional[np.ndarray] = None, sequential_sum: bool = False):
+        L = _lib.load()
+        M = len(bits)
+        self._cents = [np.ascontiguousarray(c, dtype=np.float32) for c in cents]
+        D = sum(c.shape[1] for c in self._cents)
+        self._eig = None if eig is None else np.ascontiguousarray(np.real(eig), dtype=np.float32)
+        arr = (C.POINTER(C.c_float) * M)()
+        for i, c in enumerate(self._cents):
+            arr[i] = c.ctypes.data_as(C.POINTER(C.c_float))
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        self.D, self.M = D, M
+        _lib.check_multi(L.vaqhip_multi_create(C.byref(self._h), D, M, (C.c_int * M)(*bits), arr,
+                                               _ptr(self._eig) if self._eig is not None else None,
+                                               len(devices), devs, 1 if sequential_sum else 0))
+
+    def set_codes(self, codes: np.ndarray, id_base: int = 0) -> None:
+        cb = np.ascontiguousarray(codes, dtype=np.uint16)
+        assert cb.ndim == 2 and cb.shape[1] == self.M
+        _lib.check_multi(_lib.load().vaqhip_multi_set_codes_u16(self._h, _ptr(cb), cb.shape[0], id_base))
+
+    def add_codes(self, codes: np.ndarray) -> None:
+        cb = np.ascontiguousarray(codes, dtype=np.uint16)
+        _lib.check_multi(_lib.load().vaqhip_multi_add_codes_u16(self._h, _ptr(cb), cb.shape[0]))
+
+    def set_option(self, key: str, value: int) -> None:
+        _lib.check_multi(_lib.load().vaqhip_multi_set_option(self._h, key.encode(), int(value)))
+
+    def set_method(self, methods: int, visit: float = 1.0) -> None:
+        _lib.check_multi(_lib.load().vaqhip_multi_set_method(self._h, methods, float(visit)))
+
+    def set_ti_clusters(self, clusters: Optional[np.ndarray], seg: int = 0) -> None:
+        if clusters is None:
+            _lib.check_multi(_lib.load().vaqhip_multi_set_ti_clusters(self._h, None, 0, 0))
+            return
+        cl = np.ascontiguousarray(clusters, dtype=np.float32)
+        _lib.check_multi(_lib.load().vaqhip_multi_set_ti_clusters(self._h, _ptr(cl), cl.shape[0], seg))
+
+    def search(self, XTest: np.ndarray, k: int, projected: bool = False) -> LabelDistVec:
+        X = np.ascontiguousarray(XTest, dtype=np.float32)
+        nq = X.shape[0]
+        ret = LabelDistVec(np.empty(nq * k, np.int32), np.empty(nq * k, np.float32))
+        _lib.check_multi(_lib.load().vaqhip_multi_search(self._h, _ptr(X), nq, k, 1 if projected else 0,
+                                                         _ptr(ret.labels), _ptr(ret.distances)))
+        return ret
+
+    def info(self) -> dict:
+        inf = _lib.MultiInfo()
+        _lib.check_multi(_lib.load().vaqhip_multi_get_info(self._h, C.byref(inf)))
+        n = inf.n_devices
+        return dict(n_devices=n, exchange=inf.exchange, N=inf.N, id_base=inf.id_base,
+                    device_ids=list(inf.device_ids)[:n], shard_rows=list(inf.shard_rows)[:n],
+                    last_search_ms=inf.last_search_ms, last_exchange_ms=inf.last_exchange_ms,
+                    last_merge_ms=inf.last_merge_ms)
+
+    def close(self) -> None:
+        if self._h:
+            _lib.load().vaqhip_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
