@@ -357,3 +357,21 @@ def test_gpu_ti_append_and_method_errors():
                                    lab.ctypes.data_as(C.c_void_p), dis.ctypes.data_as(C.c_void_p))
     assert rc == -7 and b"TI" in L.vaqhip_last_error()                      # ... is a state error at search
     v.close()
+
+
+@pytest.mark.gpu
+def test_cpp_from_reference_after_cluster_ti(tmp_path):
+    """include/vaqhip.hpp VaqHip::fromReference on a stand-in for the reference object AFTER its
+    clusterTI() (regrouped mCodebook + mTIClustersMember): labels must be original rows."""
+    import os
+    import subprocess
+    from vaq_amd import build
+    lib = build.build_lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "from_reference_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "from_reference_test.cpp"), "-o", exe,
+                           "-L" + os.path.dirname(lib), "-lvaqhip", "-Wl,-rpath," + os.path.dirname(lib),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "from_reference ok" in r.stdout, r.stdout + r.stderr

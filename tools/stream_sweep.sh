@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/stream_sweep.sh [variant...] -- the HBM streaming pass (one pass over 250M x 16 B random codes,
+# every bucket visited) for the main library and experiment variants, over a few launch shapes
+cd "$GRAFT_REPO_ROOT"
+run() {
+  python3 bench.py --workload c5 --rows 250000000 --random-codes --nq 2 --no-skip --seed 0 --steps 20 --warmup 3 --no-cpu --no-recall $1 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); h=d['headline_kernel']; r=d['roofline']
+print('%-28s kernel %s %.4f ms  %.0f GB/s frac %.3f  wg %d lds %d' % ('$1', h['kernel'], h['kernel_ms'], r.get('achieved') or 0, r.get('frac') or 0, h['workgroups'], h['lds_bytes']))"
+}
+echo main; for a in "" "--nwaves 4" "--nwaves 16" "--slices 4096" "--slices 1024"; do run "$a"; done
+for v in "$@"; do echo $v; export VAQHIP_LIB=$PWD/vaq_amd/lib/variants/$v/libvaqhip.so; for a in "" "--nwaves 16" "--slices 4096"; do run "$a"; done; done

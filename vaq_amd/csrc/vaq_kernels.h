@@ -101,9 +101,10 @@ struct ScanParams {
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
                           hipStream_t st);
 // cent_t: the codebooks dimension-major (entry j * ncent + c of subspace s at cent_off)
+// min_ncent: the smallest codebook (subspaces of < 8 centroids take the reference's scalar branch)
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,
                             const SubDesc *sub, const float *cent_t, int lut_floats, int max_ncent,
-                            float *lut, hipStream_t st);
+                            float *lut, hipStream_t st, int min_ncent = 1);
 hipError_t launch_lut_expand(const float *lut_packed, int nq, int M, const SubDesc *sub,
                              int lut_floats, int ksub, float *lut_ref, hipStream_t st);
 // VAQ::encodeImpl: Xp is n x D already in PCA space; codes is n x M uint16 row-major

@@ -43,6 +43,8 @@ __global__ void project_kernel(const float *__restrict__ X, int D,
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
                           hipStream_t st) {
   if (n == 0) return hipSuccess;
+  // (one workgroup per row: batching 8 rows per workgroup, as the LUT build does with queries,
+  //  was measured slower here -- 0.044 vs 0.030 ms for 10 k rows: too few workgroups to fill the chip)
   int threads = D < 256 ? ((D + 63) / 64) * 64 : 256;
   hipLaunchKernelGGL(project_kernel, dim3((unsigned)n), dim3(threads), D * sizeof(float), st, X, D,
                      E, out);
@@ -66,11 +68,12 @@ __device__ __forceinline__ float sqdiff(float x, float y) {
 __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
                                  const SubDesc *__restrict__ sub,
                                  const float *__restrict__ cent_t, int lut_floats,
-                                 float *__restrict__ lut) {
+                                 float *__restrict__ lut, int only_small) {
   extern __shared__ float qs[];
   const int q = blockIdx.x, s = blockIdx.y;
   const SubDesc sd = sub[s];
   if ((int)(blockIdx.z * blockDim.x) >= sd.ncent) return;  // chunk beyond this subspace's codebook
+  if (only_small && sd.ncent >= 8) return;                 // (the batched kernel did those)
   for (int j = threadIdx.x; j < L; j += blockDim.x) qs[j] = qproj[(size_t)q * D + (size_t)s * L + j];
   __syncthreads();
   float *out = lut + (size_t)q * lut_floats + sd.lut_off;
@@ -119,16 +122,63 @@ __global__ void lut_build_kernel(const float *__restrict__ qproj, int D, int L,
 #undef Y
 }
 
+// The same for codebooks of >= 8 centroids (VAQ.hpp:134-159), LUT_QT queries per workgroup: a
+// thread owns one centroid and reads each of its coordinates ONCE for the whole batch of queries
+// (the per-query kernel above spends its time launching 80 000 workgroups of 16 FMAs a thread
+// at C2).  Per (query, centroid) the chain is unchanged: acc = fma(diff, diff, acc), j ascending.
+constexpr int LUT_QT = 8;
+__global__ __launch_bounds__(256) void lut_build_batch_kernel(const float *__restrict__ qproj, int nq, int D, int L,
+                                                              const SubDesc *__restrict__ sub,
+                                                              const float *__restrict__ cent_t, int lut_floats,
+                                                              float *__restrict__ lut) {
+  extern __shared__ float qs[];  // [LUT_QT][L]
+  const int q0 = blockIdx.x * LUT_QT, s = blockIdx.y;
+  const SubDesc sd = sub[s];
+  const int K = sd.ncent;
+  if (K < 8) return;  // (those subspaces are the per-query kernel's)
+  for (int i = threadIdx.x; i < LUT_QT * L; i += blockDim.x) {
+    const int qt = i / L, j = i - qt * L;
+    qs[i] = q0 + qt < nq ? qproj[(size_t)(q0 + qt) * D + (size_t)s * L + j] : 0.0f;
+  }
+  __syncthreads();
+  const float *cs = cent_t + sd.cent_off;
+  for (int c = threadIdx.x; c < K; c += blockDim.x) {
+    float acc[LUT_QT];
+#pragma unroll
+    for (int qt = 0; qt < LUT_QT; qt++) acc[qt] = 0.0f;
+    for (int j = 0; j < L; j++) {
+      const float y = cs[(size_t)j * K + c];
+#pragma unroll
+      for (int qt = 0; qt < LUT_QT; qt++) {
+        const float diff = qs[qt * L + j] - y;
+        acc[qt] = __builtin_fmaf(diff, diff, acc[qt]);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < LUT_QT; qt++)
+      if (q0 + qt < nq) lut[(size_t)(q0 + qt) * lut_floats + sd.lut_off + c] = acc[qt];
+  }
+}
+
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L, const SubDesc *sub,
                             const float *cent_t, int lut_floats, int max_ncent, float *lut,
-                            hipStream_t st) {
+                            hipStream_t st, int min_ncent) {
   if (nq == 0) return hipSuccess;
+  (void)max_ncent;
+  if (nq >= 2 * LUT_QT && max_ncent >= 8) {
+    hipLaunchKernelGGL(lut_build_batch_kernel, dim3((nq + LUT_QT - 1) / LUT_QT, M), dim3(256),
+                       LUT_QT * L * sizeof(float), st, qproj, nq, D, L, sub, cent_t, lut_floats, lut);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || min_ncent >= 8) return e;
+    // codebooks of fewer than 8 centroids (the reference's scalar branch) go through the per-query kernel
+    hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M, 1), dim3(64), L * sizeof(float), st, qproj, D, L, sub, cent_t,
+                       lut_floats, lut, 1);
+    return hipGetLastError();
+  }
   // one workgroup per (query, subspace): splitting big codebooks over blockIdx.z was measured
   // slower (the extra, mostly empty workgroups cost more than the 16-iteration loop they save)
-  (void)max_ncent;
-  const int chunks = 1;
-  hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M, chunks), dim3(256), L * sizeof(float), st, qproj, D, L,
-                     sub, cent_t, lut_floats, lut);
+  hipLaunchKernelGGL(lut_build_kernel, dim3(nq, M, 1), dim3(256), L * sizeof(float), st, qproj, D, L,
+                     sub, cent_t, lut_floats, lut, 0);
   return hipGetLastError();
 }
 

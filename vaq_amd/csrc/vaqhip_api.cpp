@@ -72,7 +72,7 @@ constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to w
 
 struct vaqhip_index {
   int D = 0, M = 0, L = 0;
-  int max_bits = 0, total_bits = 0, W = 0, layout = 0, lut_floats = 0;
+  int max_bits = 0, min_bits = 0, total_bits = 0, W = 0, layout = 0, lut_floats = 0;
   int device = 0, n_cu = 256;
   std::vector<int> bits;
   std::vector<vaq::SubDesc> sub;
@@ -417,7 +417,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
+                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st,
+                                  1 << ix->min_bits));
     if (timing) HIP_TRY(hipEventRecord(ev[2], st));
     vaq::ScanParams sp;
     sp.codes = ix->d_codes.as<uint32_t>();
@@ -667,6 +668,7 @@ int vaqhip_index_create_ex(vaqhip_index **out, int D, int M, const int *bits,
     all8 = all8 && b == 8;
   }
   ix->max_bits = maxb;
+  ix->min_bits = *std::min_element(bits, bits + M);
   ix->total_bits = bit_off;
   ix->lut_floats = lut_off;
   ix->W = (bit_off + 31) / 32;
@@ -984,7 +986,8 @@ int vaqhip_build_lut(vaqhip_index *ix, const float *queries, int nq, int project
       qp = ix->w_qproj.as<float>();
     }
     HIP_TRY(vaq::launch_lut_build(qp, n, ix->D, ix->M, ix->L, ix->d_sub.as<vaq::SubDesc>(),
-                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st));
+                                  ix->d_cent_t.as<float>(), ix->lut_floats, 1 << ix->max_bits, ix->w_lut.as<float>(), st,
+                                  1 << ix->min_bits));
     HIP_TRY(vaq::launch_lut_expand(ix->w_lut.as<float>(), n, ix->M, ix->d_sub.as<vaq::SubDesc>(),
                                    ix->lut_floats, ksub, ix->w_lutref.as<float>(), st));
     HIP_TRY(hipMemcpyAsync(lut_out + (size_t)q0 * per_q, ix->w_lutref.p, (size_t)n * per_q * sizeof(float),
