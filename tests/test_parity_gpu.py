@@ -615,3 +615,30 @@ def test_two_streams_two_threads_one_index(vaqlib, oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_boundary_ties_at_c2_size(vaqlib, oracle):
+    """SIFT-1M shape (1M x 8 B, k = 100) with duplicates PLANTED at each query's k-th distance:
+    several rows tie for the last places of the result.  The reference keeps whichever its heap
+    happens to hold (utils/Heap.hpp:115-169); the contract here (DESIGN.md "Ties") is the
+    smallest labels at that distance, distances bit-exact -- on both scan forms."""
+    k, nq, N = 100, 8, 1_000_000
+    c = make_case(7321, 128, [8] * 8, N, nq)
+    Xp = oracle.project(c["X"], c["eig"])
+    rng = np.random.default_rng(1)
+    for q in range(nq):
+        d = oracle.all_dists(oracle.create_lut(Xp[q], c["cents"], 8), c["codes"])
+        kth = np.argpartition(d, k - 1)[k - 1]
+        for dst in rng.integers(0, N, size=4):  # four more rows exactly as far away as the k-th best
+            c["codes"][dst] = c["codes"][kth]
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=8)
+    ad = oracle_all_dists(oracle, c, Xp)
+    v = make_index(c)
+    for bf in (1, 0):
+        v.set_option("best_first", bf)
+        a = v.search(c["X"], k)
+        ties = assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
+                                   what=f"planted ties bf={bf}")
+        # every query has more rows at its k-th distance than places: the rule decided something
+        assert sum(int((ad[q] == a.distances.reshape(nq, k)[q, -1]).sum() > 1) for q in range(nq)) == nq
+        assert ties >= 1, ties
