@@ -299,7 +299,12 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       0 never (VAQ::searchHeap as written), 1 survivors are
  *                       compacted through an LDS queue, 2 survivors finish in
  *                       place, 3 (default) 1 or 2 chosen per search            */
-/*   "best_first"        1 (default): a one-query workgroup whose row slice spans many buckets (the
+/*   "group_queries"     1 (default): on a streamed database (> 256 MB of codes) with several
+ *                       multi-query passes, the queries are ordered by their nearest first and
+ *                       second codes before they are cut into passes -- a pass can only skip a
+ *                       bucket all of its queries can skip, and similar queries skip the same ones;
+ *                       2: always; 0: never.  Results are written to the queries' own slots.
+ *   "best_first"        1 (default): a one-query workgroup whose row slice spans many buckets (the
  *                       cache-resident databases) visits ALL of them in ascending order of their
  *                       bound, work units handed to its waves by ticket, and stops at the first
  *                       bucket out of reach ("best-first form"); 0: the

@@ -642,3 +642,27 @@ def test_boundary_ties_at_c2_size(vaqlib, oracle):
         # every query has more rows at its k-th distance than places: the rule decided something
         assert sum(int((ad[q] == a.distances.reshape(nq, k)[q, -1]).sum() > 1) for q in range(nq)) == nq
         assert ties >= 1, ties
+
+
+@pytest.mark.parametrize("bits", [[8] * 16, [12, 10, 9, 8, 8, 7, 6, 4], [8] * 8], ids=["m16", "nonuniform", "m8"])
+def test_query_grouping_is_invisible(vaqlib, oracle, bits):
+    """"group_queries": multi-query passes take the queries in the order of their nearest first
+    and second codes; every result still lands in its own query's slot (ragged last pass,
+    several slices with the pre-pass, in-place and queued forms)."""
+    c = make_case(5150, 128, bits, 300_000, 37, dup_frac=0.02)
+    v = make_index(c)
+    k = 50
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
+    ad = oracle_all_dists(oracle, c, Xp)
+    for qb, ea, slices, group in [(2, 1, 0, 2), (4, 1, 0, 2), (4, 2, 0, 2), (2, 1, 7, 2), (4, 1, 300, 2), (4, 0, 3, 2),
+                                  (4, 1, 0, 0)]:
+        v.set_option("queries_per_pass", qb)
+        v.set_option("early_abandon", ea)
+        v.set_option("slices", slices)
+        v.set_option("group_queries", group)
+        a = v.search(c["X"], k)
+        assert_topk_matches(a.labels.reshape(37, k), a.distances.reshape(37, k), o_lab, o_dis, ad,
+                            what=f"qb={qb} ea={ea} slices={slices} group={group}")
+    a1 = v.search(c["X"][:1], k)  # fewer queries than a pass holds
+    assert np.array_equal(a1.labels, a.labels[:k])

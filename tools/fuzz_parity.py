@@ -74,7 +74,8 @@ while time.time() - t0 < budget:
         opts = dict(queries_per_pass=int(rng.choice([0, 1, 2, 4])), early_abandon=int(rng.integers(0, 4)),
                     slices=int(rng.choice([0, 0, 1, 2, 5, 300])), hot_buckets=int(rng.choice([0, 3, 16, 32])),
                     waves_per_workgroup=int(rng.choice([0, 4, 8, 16])), seed_thresholds=int(rng.integers(0, 2)),
-                    ordered_slices=int(rng.integers(0, 2)), best_first=int(rng.integers(0, 3) > 0))
+                    ordered_slices=int(rng.integers(0, 2)), best_first=int(rng.integers(0, 3) > 0),
+                    group_queries=int(rng.choice([0, 1, 2, 2])))
         for key, val in opts.items():
             v.set_option(key, val)
         v.set_option("timing", 1)
@@ -95,7 +96,7 @@ while time.time() - t0 < budget:
             print("timing/plan of the failing search:", v.last_timing(), v.info())
             # which option matters: flip each one back to its default in turn
             for key2, dflt in (("best_first", 0), ("best_first", 1), ("ordered_slices", 0), ("slices", 0), ("seed_thresholds", 0),
-                               ("hot_buckets", 16), ("waves_per_workgroup", 0), ("queries_per_pass", 1)):
+                               ("hot_buckets", 16), ("waves_per_workgroup", 0), ("queries_per_pass", 1), ("group_queries", 0)):
                 v.set_option(key2, dflt)
                 b2 = v.search(c["X"], k)
                 same = np.array_equal(b2.distances.reshape(nq, k), o_dis)

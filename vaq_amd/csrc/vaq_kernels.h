@@ -73,6 +73,7 @@ struct ScanParams {
                           // larger for the sampling pre-pass)
   int share_thr;          // 1: exchange thresholds between workgroups through g_thr
   const int *slice_order; // [query batches][n_slices] best-first slice order, or nullptr = row order
+  const int *qorder;      // [nq] the i-th query a pass takes (similar queries share a pass), or nullptr = i
   int seq;                // 1: sequential row sum (BitVecEngine::queryLUT) instead of groups of 4
   int32_t *final_labels;  // non-null (needs n_slices == 1): results written directly, [nq][k]
   float *final_dist;
@@ -131,6 +132,9 @@ hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bit
 hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, const int *bstart,
                               int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,
                               int64_t n_rows, int *order, hipStream_t st);
+// order[i] = the query the i-th pass slot takes: by (nearest first code, nearest second code); nq <= 16384
+hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, int off1, int n1, int *order,
+                              hipStream_t st);
 // LDS geometry of a scan workgroup for top-k = k
 void scan_geometry(int layout, int M, int k, int ea, int *kp, int *ccap, int *qcap);
 // bytes of LDS a scan workgroup of `nwaves` wavefronts needs

@@ -499,6 +499,78 @@ hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, 
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------
+// Query grouping for multi-query passes over a streamed database.  A pass of Qb queries skips a
+// bucket only when EVERY query of the pass can skip it, so a pass costs the UNION of its queries'
+// buckets.  Queries whose nearest first and second codes agree have nearly the same buckets in
+// reach: ordering the queries by (nearest first code, nearest second code) before cutting them
+// into passes shrinks that union (125M x 16 B, 1024 queries, Qb = 4: 35.5 -> 28.0 ms).  Results
+// are written to the queries' own slots, so the caller sees no difference.
+// query_order_kernel: one workgroup; keys = (argmin of LUT table 0) << 16 | (argmin of table 1),
+// then a bitonic sort of key << 32 | query in LDS (nq <= 16384: 128 KB); order[i] = i-th query.
+// ---------------------------------------------------------------------------
+constexpr int QORDER_THREADS = 1024;
+constexpr int QORDER_MAX = 16384;
+__global__ __launch_bounds__(QORDER_THREADS) void query_order_kernel(const float *__restrict__ lut, int lut_floats, int nq,
+                                                                     int n0, int off1, int n1, int *__restrict__ order) {
+  extern __shared__ unsigned long long qk[];  // [P], P = power of two >= nq
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = QORDER_THREADS / 64;
+  int P = 2;
+  while (P < nq) P <<= 1;
+  for (int q = wave; q < P; q += nwaves) {
+    unsigned long long key = ~0ull;
+    if (q < nq) {
+      const float *l = lut + (size_t)q * lut_floats;
+      unsigned a[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int off = t == 0 ? 0 : off1, n = t == 0 ? n0 : n1;
+        // packed (value bits, index): entries are >= 0, so bit order == value order; NaN sorts last
+        unsigned long long best = ~0ull;
+        for (int e = lane; e < n; e += 64) {
+          const float x = l[off + e];
+          const unsigned long long c = ((unsigned long long)(x == x ? float_to_bits(x) : 0xffffffffu) << 32) | (unsigned)e;
+          best = c < best ? c : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long x = __shfl_xor(best, o);
+          best = x < best ? x : best;
+        }
+        a[t] = (unsigned)(best & 0xffffu);
+      }
+      key = ((unsigned long long)((a[0] << 16) | a[1]) << 32) | (unsigned)q;
+    }
+    if (lane == 0) qk[q] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += QORDER_THREADS) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const unsigned long long x = qk[i], y = qk[j];
+        if ((x > y) == ((i & size) == 0)) { qk[i] = y; qk[j] = x; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < nq; i += QORDER_THREADS) order[i] = (int)(qk[i] & 0xffffffffu);
+}
+
+hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, int off1, int n1, int *order,
+                              hipStream_t st) {
+  if (nq <= 0 || nq > QORDER_MAX) return hipErrorInvalidValue;
+  int P = 2;
+  while (P < nq) P <<= 1;
+  const size_t lds = (size_t)P * sizeof(unsigned long long);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(query_order_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(query_order_kernel, dim3(1), dim3(QORDER_THREADS), lds, st, lut, lut_floats, nq, n0, off1, n1, order);
+  return hipGetLastError();
+}
+
 // __global__ entry points: the SGPR-capped one for EA_NONE / EA_QUEUE, a plain one for EA_INPLACE
 static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
 

@@ -446,7 +446,8 @@ template <int QB, bool SQ> struct ScanCtx {
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       const int x = qbatch * QB + q;
-      qi[q] = x < p.nq ? x : p.nq - 1;
+      const int xc = x < p.nq ? x : p.nq - 1;
+      qi[q] = p.qorder ? p.qorder[xc] : xc;  // (similar queries are grouped into a pass)
       sel[q] = sel_view(smem + off + (size_t)q * sb, p.kp, p.ccap);
       thr_d[q] = FLT_MAX;
       thr_s[q] = FLT_MAX;
@@ -750,7 +751,7 @@ template <int QB, bool SQ> struct ScanCtx {
         if (p.final_labels) {
           // one slice per query: this list IS the result -- write it in the API's
           // format (heap_reorder's: ascending, empty slots -1 / FLT_MAX) and skip the merge
-          const size_t o = (size_t)x * k;
+          const size_t o = (size_t)qi[q] * k;
           for (int i = lane; i < k; i += 64) {
             const int id = sel[q].id[i];
             const bool ok = id != ID_SENTINEL;
@@ -758,12 +759,12 @@ template <int QB, bool SQ> struct ScanCtx {
             p.final_dist[o + i] = ok ? sel[q].d[i] : FLT_MAX;
           }
         } else {
-          const size_t o = ((size_t)x * p.n_slices + slice) * k;
+          const size_t o = ((size_t)qi[q] * p.n_slices + slice) * k;
           for (int i = lane; i < k; i += 64) {
             p.part_d[o + i] = sel[q].d[i];
             p.part_id[o + i] = sel[q].id[i];
           }
-          if (lane == 0) p.part_cnt[(size_t)x * p.n_slices + slice] = (int)sel[q].hdr[SEL_NBEST];
+          if (lane == 0) p.part_cnt[(size_t)qi[q] * p.n_slices + slice] = (int)sel[q].hdr[SEL_NBEST];
         }
       }
     }

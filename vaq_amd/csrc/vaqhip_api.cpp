@@ -88,7 +88,7 @@ struct vaqhip_index {
   unsigned methods = VAQHIP_METHOD_HEAP;
   DevBuf d_ti_clusters, d_ti_clusters_t, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
   // workspace (grow-only, reused across searches)
-  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order;
+  DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order, w_qorder;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
   // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
@@ -98,7 +98,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -464,6 +464,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.final_labels = nullptr;
     sp.final_dist = nullptr;
     sp.slice_order = nullptr;
+    sp.qorder = nullptr;
     sp.id_base = ix->id_base;
     sp.ti = 0;
     sp.ti_order = nullptr;
@@ -474,6 +475,17 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.ti_cap = 0;
     sp.sqrt_out = 0;
     int grid = 0;
+    // Multi-query passes over a streamed database: put queries with the same nearest first and
+    // second codes into the same pass (a pass visits the union of its queries' buckets).
+    // "group_queries": 1 = when it pays (streamed codes, several passes), 2 = always, 0 = never.
+    if (!ti && pl.qb > 1 && ix->M > 1 && n <= 16384 && !pl.ordered &&
+        (ix->opt_group == 2 ||
+         (ix->opt_group == 1 && n >= 4 * pl.qb && (double)ix->N * ((ix->total_bits + 7) / 8) > 256e6))) {
+      HIP_TRY(ix->w_qorder.ensure((size_t)n * sizeof(int)));
+      HIP_TRY(vaq::launch_query_order(ix->w_lut.as<float>(), ix->lut_floats, n, ix->sub[0].ncent, ix->sub[1].lut_off,
+                                      ix->sub[1].ncent, ix->w_qorder.as<int>(), st));
+      sp.qorder = ix->w_qorder.as<int>();
+    }
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
     if (ti) {
@@ -736,7 +748,7 @@ void vaqhip_index_destroy(vaqhip_index *ix) {
     for (DevBuf *b : {&ix->d_cent, &ix->d_cent_t, &ix->d_eig, &ix->d_sub, &ix->d_first_sub, &ix->d_codes, &ix->d_perm,
                       &ix->d_bstart, &ix->w_q,
                       &ix->w_qproj, &ix->w_lut, &ix->w_part_d, &ix->w_part_id, &ix->w_part_cnt, &ix->w_labels,
-                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id, &ix->w_order})
+                      &ix->w_dist, &ix->w_stage, &ix->w_lutref, &ix->w_thr, &ix->w_ms_d, &ix->w_ms_id, &ix->w_order, &ix->w_qorder})
       b->release();
   }
   delete ix;
@@ -1258,6 +1270,9 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "bucket_bits") {
     if (value < 0 || value > 12) return fail(VAQHIP_EINVAL, "bucket_bits must be 0..12");
     ix->opt_bucket_bits = (int)value;  // takes effect when the codes are (re)set
+  } else if (k == "group_queries") {
+    if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "group_queries must be 0, 1 or 2");
+    ix->opt_group = (int)value;
   } else if (k == "best_first") {
     ix->opt_bf = value != 0;
   } else if (k == "seed_thresholds") {
