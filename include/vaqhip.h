@@ -111,9 +111,12 @@ int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_
 
 /* Append n_new rows (same layout) behind the rows already in the index; their labels
  * continue at id_base + N.  Stands for growing `mCodebook` and calling the setter again
- * (SURVEY.md section 8b lists the entry point as `add_codes`): the rows are re-ordered as a
- * whole (bucketed or TI order), so an append costs a rebuild of the packed copy -- O(N) on
- * the GPU, with a temporary of 2*M bytes per row.  Synchronises. */
+ * (SURVEY.md section 8b lists the entry point as `add_codes`).  A bucketed index sorts and packs
+ * the NEW rows only and merges them into the existing order bucket by bucket: the packed rows and
+ * their labels are copied once, nothing is unpacked or re-sorted, temporaries are O(n_new) plus
+ * the new packed buffer; the bucket key width stays the one chosen when the codes were set.  A
+ * TI-grouped index (rows ordered by cluster and centre distance) is rebuilt as a whole.
+ * Synchronises. */
 int vaqhip_index_add_codes_u16(vaqhip_index *ix, const uint16_t *codes_rowmajor, int64_t n_new);
 int vaqhip_index_add_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes_rowmajor,
                                       int64_t n_new, void *stream);

@@ -527,6 +527,21 @@ def test_add_codes_appends_rows(vaqlib, oracle):
         a = v.search(c["X"], k)
         assert_topk_matches(a.labels.reshape(8, k), a.distances.reshape(8, k), o_lab, o_dis, ad, what="appended")
         v.close()
+        # many small appends (merged into the bucketed order, never rebuilt) == one index, bit for bit
+        rng = np.random.default_rng(4)
+        cuts = np.sort(rng.choice(np.arange(12000, 30000), size=9, replace=False)).tolist() + [30000]
+        w = make_index(dict(c, codes=full[:12000]))
+        w.search(c["X"], k)
+        lo = 12000
+        for hi in cuts:
+            w.add_codes(full[lo:hi])
+            lo = hi
+        ref = make_index(dict(c, codes=full)).search(c["X"], k)
+        for slices in (0, 3):
+            w.set_option("slices", slices)
+            b = w.search(c["X"], k)
+            assert np.array_equal(b.labels, ref.labels) and np.array_equal(b.distances, ref.distances), slices
+        w.close()
 
 
 @pytest.mark.parametrize("bits", [[8] * 12, [8] * 8, [12, 10, 9, 8, 8, 7, 6, 4]], ids=["m12", "m8", "nonuniform"])

@@ -128,6 +128,12 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 // occurs, -1 otherwise; the caller back-fills).  Synchronises the stream.
 hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift, int bits1,
                               int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st);
+// Appending: merge the (separately sorted and packed) new rows into the bucketed order, bucket by
+// bucket; *_start have K0 + 1 entries (back-filled); out_* are the new buffers
+hipError_t launch_merge_rows(const uint32_t *old_codes, const uint32_t *old_perm, const int *old_start,
+                             const uint32_t *new_codes, const uint32_t *new_perm, const int *new_start, int K0,
+                             int64_t n_old, int64_t n_total, int M, int layout, int W, uint32_t *out_codes,
+                             uint32_t *out_perm, hipStream_t st);
 // Best-first slice order per query batch (n_slices <= 4096, n_buckets <= 4096)
 hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, const int *bstart,
                               int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,

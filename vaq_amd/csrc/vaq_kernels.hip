@@ -264,6 +264,56 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
   return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------
+// Appending rows to a bucketed index without rebuilding it: the new rows are sorted and packed
+// on their own (sort_by_first_code + pack_codes, n_new rows), then merged bucket by bucket --
+// bucket b of the result = bucket b of the old order followed by bucket b of the new rows (new
+// labels are larger, so this IS the stable order a sort of all rows would give).  One thread per
+// output row copies the row's packed words and its label; no unpacking, no global re-sort.
+//   tot_start[b] = old_start[b] + new_start[b]   (K0 + 1 entries each)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int64_t packed_word_index(int64_t row, int w, int layout, int WPR) {
+  if (layout == LAYOUT_BYTES) return row * WPR + w;
+  return (row / TILE_ROWS) * (int64_t)(TILE_ROWS * WPR) + (int64_t)w * TILE_ROWS + (row % TILE_ROWS);
+}
+
+__global__ void merge_rows_kernel(const uint32_t *__restrict__ old_codes, const uint32_t *__restrict__ old_perm,
+                                  const int *__restrict__ old_start, const uint32_t *__restrict__ new_codes,
+                                  const uint32_t *__restrict__ new_perm, const int *__restrict__ new_start, int K0,
+                                  int64_t n_old, int64_t n_total, int layout, int WPR, uint32_t *__restrict__ out_codes,
+                                  uint32_t *__restrict__ out_perm) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_total) return;
+  // bucket of output row r: largest b with old_start[b] + new_start[b] <= r
+  int lo = 0, hi = K0;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)old_start[mid] + new_start[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  const int b = lo;
+  const int64_t off = r - ((int64_t)old_start[b] + new_start[b]);
+  const int64_t old_cnt = (int64_t)old_start[b + 1] - old_start[b];
+  const bool from_old = off < old_cnt;
+  const int64_t src = from_old ? old_start[b] + off : new_start[b] + (off - old_cnt);
+  const uint32_t *codes = from_old ? old_codes : new_codes;
+  for (int w = 0; w < WPR; w++)
+    out_codes[packed_word_index(r, w, layout, WPR)] = codes[packed_word_index(src, w, layout, WPR)];
+  out_perm[r] = from_old ? old_perm[src] : (uint32_t)(n_old + new_perm[src]);
+}
+
+hipError_t launch_merge_rows(const uint32_t *old_codes, const uint32_t *old_perm, const int *old_start,
+                             const uint32_t *new_codes, const uint32_t *new_perm, const int *new_start, int K0,
+                             int64_t n_old, int64_t n_total, int M, int layout, int W, uint32_t *out_codes,
+                             uint32_t *out_perm, hipStream_t st) {
+  if (n_total <= 0) return hipSuccess;
+  const int WPR = layout == LAYOUT_BYTES ? M / 4 : W;
+  hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, st, old_codes, old_perm,
+                     old_start, new_codes, new_perm, new_start, K0, n_old, n_total, layout, WPR, out_codes, out_perm);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Bucketed row order.  The index stores rows stably sorted by (the top bits
 // of) the code of subspace 0 -- after PCA the highest-variance subspace.  A

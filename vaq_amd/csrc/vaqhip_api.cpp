@@ -81,6 +81,7 @@ struct vaqhip_index {
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
   int bucket_shift = 0, bucket_t = 0, n_buckets = 1;  // bucketed row order (set with the codes)
   int64_t N = -1, id_base = 0;
+  int64_t N_keyed = 0;  // rows the bucket key width was chosen for (appends rebuild once N outgrows it 4x)
   // triangle-inequality form (VAQ::clusterTI): rows grouped by cluster instead of by first
   // code; d_bstart then holds the cluster starts, n_buckets = ti_T, bucket_shift = 0
   int ti_T = 0, ti_seg = 0;
@@ -806,6 +807,7 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   }
   HIP_TRY(hipMemcpy(ix->d_bstart.p, bstart.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
   ix->N = N;
+  ix->N_keyed = N;
   ix->bucket_shift = shift;
   ix->bucket_t = bt;
   ix->n_buckets = K0;
@@ -841,8 +843,55 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   return VAQHIP_OK;
 }
 
-// append: recover the rows already packed (original order), put the new ones behind them,
-// regroup everything (the bucketed / TI order is global, so an append is a rebuild)
+// append to a bucketed (non-TI) index: sort and pack the NEW rows only, then merge them into the
+// existing order bucket by bucket (launch_merge_rows).  O(N) bytes are copied once -- the packed
+// rows and their labels -- but nothing is unpacked and nothing is re-sorted; temporaries are
+// O(n_new) plus the new packed buffer.
+static int append_rows_bucketed(vaqhip_index *ix, const uint16_t *d_new, int64_t n_new, hipStream_t st) {
+  const int64_t n_old = ix->N, N = n_old + n_new;
+  const int K0 = ix->n_buckets;
+  const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
+  const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
+  // the new rows in bucketed order among themselves
+  DevBuf new_perm, new_start, new_codes, out_codes, out_perm;
+  HIP_TRY(new_perm.ensure((size_t)n_new * sizeof(uint32_t)));
+  HIP_TRY(new_start.ensure((size_t)(K0 + 1) * sizeof(int)));
+  HIP_TRY(vaq::sort_by_first_code(d_new, n_new, ix->M, ix->bits[0], ix->bucket_shift, ix->M > 1 ? ix->bits[1] : 0,
+                                  ix->bucket_t, new_perm.as<uint32_t>(), new_start.as<int>(), st));
+  std::vector<int> ns((size_t)K0 + 1), os((size_t)K0 + 1), ts((size_t)K0 + 1);
+  HIP_TRY(hipMemcpy(ns.data(), new_start.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  ns[K0] = (int)n_new;
+  for (int b = K0 - 1; b >= 0; b--)
+    if (ns[b] < 0) ns[b] = ns[b + 1];
+  HIP_TRY(hipMemcpy(new_start.p, ns.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(os.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  const int64_t new_padded = std::max<int64_t>(step, ((n_new + step - 1) / step) * step);
+  HIP_TRY(new_codes.ensure((size_t)vaq::packed_words(new_padded, ix->M, ix->layout, ix->W) * sizeof(uint32_t)));
+  HIP_TRY(vaq::launch_pack_codes(d_new, 0, n_new, new_padded, ix->M, ix->layout, ix->W, dsub, new_perm.as<uint32_t>(),
+                                 new_codes.as<uint32_t>(), st));
+  // the merged buffers
+  const int64_t padded = std::max<int64_t>(step, ((N + step - 1) / step) * step);
+  const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
+  HIP_TRY(out_codes.ensure((size_t)words * sizeof(uint32_t)));
+  HIP_TRY(out_perm.ensure((size_t)N * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(out_codes.p, 0, (size_t)words * sizeof(uint32_t), st));  // (the padding rows must be zero)
+  HIP_TRY(vaq::launch_merge_rows(ix->d_codes.as<uint32_t>(), ix->d_perm.as<uint32_t>(), ix->d_bstart.as<int>(),
+                                 new_codes.as<uint32_t>(), new_perm.as<uint32_t>(), new_start.as<int>(), K0, n_old, N,
+                                 ix->M, ix->layout, ix->W, out_codes.as<uint32_t>(), out_perm.as<uint32_t>(), st));
+  for (int b = 0; b <= K0; b++) ts[b] = os[b] + ns[b];
+  HIP_TRY(hipStreamSynchronize(st));
+  std::swap(ix->d_codes.p, out_codes.p);
+  std::swap(ix->d_codes.cap, out_codes.cap);
+  std::swap(ix->d_perm.p, out_perm.p);
+  std::swap(ix->d_perm.cap, out_perm.cap);
+  HIP_TRY(hipMemcpy(ix->d_bstart.p, ts.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+  ix->N = N;
+  return VAQHIP_OK;
+}
+
+// append: a bucketed index merges the new rows in (above); a TI-grouped index (rows ordered by
+// cluster and distance to the centre) and an empty index are rebuilt: recover the rows already
+// packed (original order), put the new ones behind them, regroup everything
 static int add_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_device, int64_t n_new,
                             hipStream_t st) {
   if (!ix) return fail(VAQHIP_EINVAL, "index is null");
@@ -856,6 +905,20 @@ static int add_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
   DeviceGuard g(ix->device);
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
   if (n_new == 0 && ix->N >= 0) return VAQHIP_OK;
+  {
+    int rc = ws_acquire(ix, st);  // (a search on another stream may still be reading the codes)
+    if (rc) return rc;
+  }
+  if (ix->ti_T == 0 && n_old > 0 && n_new > 0 && N < 4 * std::max<int64_t>(ix->N_keyed, 4096)) {
+    DevBuf staged;
+    const uint16_t *d_new = codes;
+    if (!on_device) {
+      HIP_TRY(staged.ensure((size_t)n_new * ix->M * sizeof(uint16_t)));
+      HIP_TRY(hipMemcpyAsync(staged.p, codes, (size_t)n_new * ix->M * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+      d_new = staged.as<uint16_t>();
+    }
+    return append_rows_bucketed(ix, d_new, n_new, st);  // synchronises
+  }
   DevBuf rows;
   HIP_TRY(rows.ensure(std::max<size_t>((size_t)N * ix->M * sizeof(uint16_t), 16)));
   if (n_old > 0)
