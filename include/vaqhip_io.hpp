@@ -117,6 +117,68 @@ inline RowMatrixF readBVecs(const std::string &p, int N, int maxRow = -1, int pa
 }
 inline RowMatrix<int> readIVecs(const std::string &p, int N) { return readVecs<int, int>(p, N); }
 
+
+// ---------------------------------------------------------------------------
+// BitVector-packed rows in the reference's convention: `bitvectors` =
+// rows of 64-bit words (BitVector.hpp:13-22), field s occupying bits [P_s, P_s + b_s) counted
+// from the MOST significant bit of word 0, P_s = sum of the bits before it; in-word placement
+// `code << (64 - (P_s % 64) - b_s)`, a field that straddles two words split high part first
+// (the packer of BitVecEngine.hpp:564-588).  The index itself packs rows LSB-first in 32-bit
+// words (a fixed permutation chosen for the GPU's field extraction) and takes
+// `CodebookType`; these two functions convert between that matrix and the reference's packed
+// form for callers that keep codes packed.  Words per row: actualBitVLen = (sum bits + 63) / 64.
+// ---------------------------------------------------------------------------
+inline size_t packedWordsPerRow(const std::vector<int> &bits) {
+  size_t t = 0;
+  for (int b : bits) t += (size_t)b;
+  return (t + 63) / 64;
+}
+
+inline std::vector<uint64_t> packRowsMSB(const CodebookType &codes, const std::vector<int> &bits) {
+  const size_t W = packedWordsPerRow(bits);
+  std::vector<uint64_t> out(codes.rows() * W, 0ull);
+  for (size_t i = 0; i < codes.rows(); i++) {
+    size_t pos = 0;
+    for (size_t s = 0; s < bits.size(); s++) {
+      const int b = bits[s];
+      const uint64_t bucket = (uint64_t)codes(i, s) & ((b >= 64) ? ~0ull : ((1ull << b) - 1ull));
+      const size_t w = pos / 64;
+      if (b > 0 && w != (pos + b - 1) / 64) {  // sliced
+        const int right = b - (int)((w + 1) * 64 - pos);
+        out[i * W + w] |= bucket >> right;
+        out[i * W + w + 1] |= (bucket & ((1ull << right) - 1ull)) << (64 - right);
+      } else if (b > 0) {
+        out[i * W + w] |= bucket << (64 - (pos % 64) - b);
+      }
+      pos += (size_t)b;
+    }
+  }
+  return out;
+}
+
+inline CodebookType unpackRowsMSB(const uint64_t *packed, size_t N, const std::vector<int> &bits) {
+  const size_t W = packedWordsPerRow(bits);
+  CodebookType codes(N, bits.size());
+  for (size_t i = 0; i < N; i++) {
+    size_t pos = 0;
+    for (size_t s = 0; s < bits.size(); s++) {
+      const int b = bits[s];
+      const size_t w = pos / 64;
+      uint64_t v = 0;
+      if (b > 0 && w != (pos + b - 1) / 64) {
+        const int right = b - (int)((w + 1) * 64 - pos);
+        const int left = b - right;
+        v = ((packed[i * W + w] & ((1ull << left) - 1ull)) << right) | (packed[i * W + w + 1] >> (64 - right));
+      } else if (b > 0) {
+        v = (packed[i * W + w] >> (64 - (pos % 64) - b)) & ((1ull << b) - 1ull);
+      }
+      codes(i, s) = (uint16_t)v;
+      pos += (size_t)b;
+    }
+  }
+  return codes;
+}
+
 inline void writeKNNResults(const std::string &path, const LabelDistVecF &results, size_t nrows) {
   const size_t k = nrows ? results.labels.size() / nrows : 0;
   std::ofstream out(path);

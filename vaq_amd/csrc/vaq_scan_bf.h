@@ -2,23 +2,28 @@
 // VAQ.cpp:1694-1727; results identical to VAQ::searchHeap, :1729-1758), one query per
 // workgroup.  Chosen by the host when a workgroup's row slice spans many buckets (rows sharing
 // their first code): the cache-resident databases, where the scan is bound by instruction issue
-// and by the serial k-min, not by memory.
+// and by the serial k-min, not by memory.  Byte codes (BfBytes) and bit-packed rows (BfBits)
+// share the scaffold scan_bf_body; DESIGN.md section 4, "Best-first form".
 //
-//  * The workgroup sorts ALL buckets of its slice by the lower bound of their row sums (the
-//    first lookup-table term) and cuts them into work units of BF_SEG_STEPS wave steps.  Waves
-//    pull units from one LDS ticket, nearest bucket first.  Thresholds only move down and the
-//    bounds only go up along that order, so the first unit whose bound exceeds the wave's
-//    threshold ends the wave's scan: no bucket is tested twice, none is walked past, and the
-//    waves finish together whatever the sizes of the buckets.
-//  * Rows that survive every partial-sum test are appended to a WAVE-PRIVATE candidate buffer
-//    (no lock, LDS is in order per wave).  When BF_FLUSH_AT have gathered, the wave reads their
-//    labels in one go (one global-memory latency for the batch), takes the workgroup lock,
-//    re-tests them against the exact (distance, label) threshold and appends the survivors to
-//    the workgroup's pool: an unsorted k-min whose threshold moves only when it fills up
-//    (pool_compact below).  The admission rule is vaq_scan.h's: admit iff strictly below the
-//    threshold in (distance, label) order.
-// Arithmetic per row is scan_bytes_body's: dism = l0; dism += l1; dism += l2; dism += l3;
-// dist += dism, group by group (VAQ.cpp:1737-1748).
+//  * Bootstrap: before anything is merged, the waves sum a few steps of the NEAREST bucket's
+//    rows completely; the q-th smallest of each wave's 64 lane minima, maximised over the waves,
+//    has at least k rows at or below it -- a valid first threshold.
+//  * Order: every bucket whose lower bound (first lookup-table term, ...) is not above the
+//    threshold joins a ROUND (at most BF_ROUND_BUCKETS, the nearest first when there are more),
+//    rank-sorted by bound and cut into work units of BF_SEG_STEPS wave steps.  Waves pull units
+//    from one LDS ticket.  Thresholds only move down and the bounds only go up along that order,
+//    so the first unit whose bound exceeds a wave's threshold ends its scan: no bucket is tested
+//    twice, none is walked past, and the waves finish together whatever the bucket sizes.
+//  * k-min: rows that survive every partial-sum test are appended to a WAVE-PRIVATE candidate
+//    buffer (no lock, LDS is in order per wave).  When BF_FLUSH_AT have gathered, the wave reads
+//    their labels in one go (one global-memory latency for the batch), takes the workgroup lock
+//    for a few LDS words, re-tests them against the exact (distance, label) threshold and appends
+//    the survivors to the workgroup's unsorted pool; a 64-bin histogram of the admitted distances
+//    moves the threshold between the (rare) exact compactions of the pool, and the pool is cut to
+//    the k best and sorted once, at the end.  The admission rule is vaq_scan.h's: admit iff
+//    strictly below the threshold in (distance, label) order.
+// Arithmetic per row is scan_bytes_body's / scan_bits_body's: dism = l0; dism += l1; dism += l2;
+// dism += l3; dist += dism, group by group (VAQ.cpp:1737-1748).
 #ifndef VAQ_SCAN_BF_H_
 #define VAQ_SCAN_BF_H_
 

@@ -82,3 +82,44 @@ def write_vecs(path: str, a: np.ndarray) -> None:
         for i in range(n):
             f.write(np.int32(d).tobytes())
             f.write(a[i].tobytes())
+
+
+def pack_rows_msb(codes: np.ndarray, bits) -> np.ndarray:
+    """CodebookType (N x M uint16) -> the reference's BitVector-packed rows (N x W uint64): field s
+    at bits [P_s, P_s + b_s) from the MSB of word 0, straddling fields split high part first
+    (BitVecEngine.hpp:564-588; include/vaqhip_io.hpp:packRowsMSB is the C++ twin)."""
+    codes = np.asarray(codes, dtype=np.uint64)
+    n = codes.shape[0]
+    W = (int(sum(bits)) + 63) // 64
+    out = np.zeros((n, W), dtype=np.uint64)
+    pos = 0
+    for s, b in enumerate(bits):
+        v = codes[:, s] & np.uint64((1 << b) - 1)
+        w = pos // 64
+        if w != (pos + b - 1) // 64:  # sliced
+            right = b - ((w + 1) * 64 - pos)
+            out[:, w] |= v >> np.uint64(right)
+            out[:, w + 1] |= (v & np.uint64((1 << right) - 1)) << np.uint64(64 - right)
+        else:
+            out[:, w] |= v << np.uint64(64 - (pos % 64) - b)
+        pos += b
+    return out
+
+
+def unpack_rows_msb(packed: np.ndarray, bits) -> np.ndarray:
+    """Inverse of pack_rows_msb: N x W uint64 -> N x M uint16."""
+    packed = np.asarray(packed, dtype=np.uint64)
+    n = packed.shape[0]
+    out = np.zeros((n, len(bits)), dtype=np.uint16)
+    pos = 0
+    for s, b in enumerate(bits):
+        w = pos // 64
+        if w != (pos + b - 1) // 64:
+            right = b - ((w + 1) * 64 - pos)
+            left = b - right
+            v = ((packed[:, w] & np.uint64((1 << left) - 1)) << np.uint64(right)) | (packed[:, w + 1] >> np.uint64(64 - right))
+        else:
+            v = (packed[:, w] >> np.uint64(64 - (pos % 64) - b)) & np.uint64((1 << b) - 1)
+        out[:, s] = v.astype(np.uint16)
+        pos += b
+    return out
