@@ -106,10 +106,13 @@ def base_chunk(c, N, dev):
 
 
 def build_index(bits, N, lo, hi, dev, device_index, world, rank, iters, random_codes=False, ti=None,
-                bucket_bits=0, keep_host_rows=0):
+                bucket_bits=0, keep_host_rows=0, gt_queries=None, gt_k=100):
     """Train (harness: PCA + k-means on the first chunk; rank 0's state is broadcast), encode
     rows [lo, hi) with the product's own encoder and hand them to a VaqHip index.
-    Returns (index, host uint16 copy of the first keep_host_rows rows or None, cents, ti info)."""
+    Returns (index, host uint16 copy of the first keep_host_rows rows or None, cents, ti info).
+    gt_queries (raw vectors): exact L2 top-gt_k of these queries over rows [lo, hi) is accumulated
+    chunk by chunk WHILE the base vectors are generated (a 1B-row base is never generated twice);
+    left in build_index.ground_truth = (squared distances, global row ids) on this rank."""
     import torch.distributed as dist
     import vaq_amd
     from vaq_amd import harness
@@ -136,6 +139,13 @@ def build_index(bits, N, lo, hi, dev, device_index, world, rank, iters, random_c
     v.id_base = lo
 
     codes = torch.empty((n_local, M), dtype=torch.int16, device=dev)
+    build_index.ground_truth = None
+    gt_d = gt_i = qq = None
+    if gt_queries is not None and not random_codes:
+        nqg = gt_queries.shape[0]
+        gt_d = torch.full((nqg, gt_k), float("inf"), device=dev)
+        gt_i = torch.full((nqg, gt_k), -1, dtype=torch.long, device=dev)
+        qq = (gt_queries * gt_queries).sum(1, keepdim=True)
     if not random_codes:
         c0, c1 = lo // GEN, ((hi + GEN - 1) // GEN if hi > lo else lo // GEN)
         for c in range(c0, c1):
@@ -144,7 +154,17 @@ def build_index(bits, N, lo, hi, dev, device_index, world, rank, iters, random_c
             xs = X[a - c * GEN: b - c * GEN]
             # the product's own encoder (VAQ::encode on the GPU; projects with eig first)
             codes[a - lo: b - lo] = v.encode_device(xs.contiguous(), projected=False)
+            if gt_d is not None and xs.shape[0] > 0:
+                d = qq - 2.0 * gt_queries @ xs.T + (xs * xs).sum(1).unsqueeze(0)
+                dv, di = torch.topk(d, min(gt_k, xs.shape[0]), dim=1, largest=False)
+                cat_d = torch.cat([gt_d, dv], 1)
+                cat_i = torch.cat([gt_i, di + a], 1)
+                sel = torch.topk(cat_d, gt_k, dim=1, largest=False)
+                gt_d, gt_i = sel.values, torch.gather(cat_i, 1, sel.indices)
+                del d, dv, di, cat_d, cat_i
             del X, xs
+        if gt_d is not None:
+            build_index.ground_truth = (gt_d, gt_i)
     else:
         g = torch.Generator(device=dev).manual_seed(harness.SEED + rank)
         step_rows = 1 << 24
@@ -229,13 +249,15 @@ def c5_leg(args, dev, device_index, k):
     from vaq_amd import harness
     bits = [8] * 16
     N = args.c5_rows
+    nq_full = 10_000
+    queries = harness.sift_like(nq_full, D, stream=7, device=dev)
     t0 = time.time()
-    v, _, _, _ = build_index(bits, N, 0, N, dev, device_index, 1, 0, iters=8)
+    v, _, _, _ = build_index(bits, N, 0, N, dev, device_index, 1, 0, iters=8,
+                             gt_queries=None if args.no_recall else queries[:100].contiguous(), gt_k=k)
+    gt = build_index.ground_truth
     info = v.info()
     build_s = time.time() - t0
     log(f"[c5 leg] index of {N} rows built in {build_s:.1f}s")
-    nq_full = 10_000
-    queries = harness.sift_like(nq_full, D, stream=7, device=dev)
     q2 = queries[:2].contiguous()
     out2 = (torch.empty((2, k), dtype=torch.int32, device=dev), torch.empty((2, k), dtype=torch.float32, device=dev))
 
@@ -311,6 +333,12 @@ def c5_leg(args, dev, device_index, k):
     }
     assert bool(torch.equal(outf[0][:2], stream_labels) and torch.equal(outf[1][:2], stream_dists)), \
         "c5 leg: the 10k-query batch and the streaming pass disagree on the first two queries"
+    if gt is not None:
+        lab = outf[0][:100].cpu().numpy()
+        scale_base["recall"] = {
+            "recall_at_100": round(harness.avg_recall(lab, gt[1].cpu().numpy()), 4),
+            "recall_1nn_in_100": round(harness.recall_at_r(lab, gt[1].cpu().numpy()), 4), "queries": 100,
+            "ground_truth": "exact L2 brute force over all %d rows, accumulated while the base was generated" % N}
     v.close()
     del v
     torch.cuda.empty_cache()
@@ -364,14 +392,18 @@ def main():
         ti = (parts[0], parts[1] if len(parts) > 1 else 0, args.visit)
     small = wl in ("c2", "c3")
     want_cpu = rank == 0 and not args.no_cpu and world == 1
+    real_codes = not args.random_codes
+    # replicas: every rank draws its own query batch (disjoint generator streams)
+    queries = harness.sift_like(nq, D, stream=7 + (100 * rank if replicas else 0), device=dev)
+    # big bases: the exact ground truth of the first queries is accumulated while the base is generated
+    RECALL_Q = min(nq, 100)
+    big_gt = (not args.no_recall and real_codes and N > 4_000_000 and not replicas and mode == "rows")
     v, host_codes, cents, (ti_T, ti_seg) = build_index(
         bits, N, lo, hi, dev, local_rank, world, rank, iters=15 if small else 8,
         random_codes=args.random_codes, ti=ti, bucket_bits=args.bucket_bits,
-        keep_host_rows=(1_000_000 if small else 4_000_000) if want_cpu else 0)
-    real_codes = not args.random_codes
-
-    # replicas: every rank draws its own query batch (disjoint generator streams)
-    queries = harness.sift_like(nq, D, stream=7 + (100 * rank if replicas else 0), device=dev)
+        keep_host_rows=(1_000_000 if small else 4_000_000) if want_cpu else 0,
+        gt_queries=queries[:RECALL_Q].contiguous() if big_gt else None, gt_k=k)
+    shard_gt = build_index.ground_truth
     q_lo, q_hi = (0, nq) if (mode == "rows" or replicas) else sharding.shard_bounds(nq, world, rank)
     my_queries = queries[q_lo:q_hi].contiguous()
     nq_local = q_hi - q_lo
@@ -528,6 +560,26 @@ def main():
             "recall_1nn_in_100": round(harness.recall_at_r(labels[:nq_r].cpu().numpy(), gt.cpu().numpy()), 4),
             "queries": nq_r, "ground_truth": "exact L2 brute force (torch) on the same synthetic base",
         }
+
+    if big_gt and shard_gt is not None:
+        gd, gi = shard_gt
+        if world > 1:  # the shards' exact top-k -> the global one
+            all_d = [torch.empty_like(gd) for _ in range(world)]
+            all_i = [torch.empty_like(gi) for _ in range(world)]
+            dist.all_gather(all_d, gd)
+            dist.all_gather(all_i, gi)
+            cat_d, cat_i = torch.cat(all_d, 1), torch.cat(all_i, 1)
+            sel = torch.topk(cat_d, k, dim=1, largest=False)
+            gi = torch.gather(cat_i, 1, sel.indices)
+        if rank == 0:
+            lab = labels[:RECALL_Q].cpu().numpy()
+            recall = {
+                "recall_at_100": round(harness.avg_recall(lab, gi.cpu().numpy()), 4),
+                "recall_1nn_in_100": round(harness.recall_at_r(lab, gi.cpu().numpy()), 4),
+                "queries": RECALL_Q,
+                "ground_truth": "exact L2 brute force (torch) over all %d rows, accumulated chunk by chunk "
+                                "while the base was generated" % N,
+            }
 
     # --------------------------------------------------------- cpu baseline --
     cpu = None
