@@ -20,7 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 po.build(ref=False)
-t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0; n_ti = 0; n_bf = 0; t_print = t0
+t0 = time.time(); n_cases = 0; n_searches = 0; ties = 0; n_ti = 0; n_bf = 0; n_append = 0; n_multi = 0; t_print = t0
 
 
 def visited_dists(c, ti, T, seg, visit, k, Xp):
@@ -67,6 +67,13 @@ while time.time() - t0 < budget:
     if rng.integers(0, 2):  # bucket key width (incl. keys that continue into the second code)
         v._ensure_index()
         v.set_option("bucket_bits", int(rng.integers(1, 13)))
+    if N >= 500 and rng.integers(0, 4) == 0:  # the same rows arriving in pieces (vaqhip_index_add_codes_u16)
+        cuts = sorted(set(int(x) for x in rng.integers(1, N, size=int(rng.integers(1, 4))))) + [N]
+        v.mCodebook = c["codes"][:cuts[0]]
+        v._ensure_codes()
+        for a_, b_ in zip(cuts[:-1], cuts[1:]):
+            v.add_codes(c["codes"][a_:b_])
+        n_append += 1
     Xp = po.project(c["X"], c["eig"]) if c["eig"] is not None else c["X"]
     o_lab, o_dis = po.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
     ad = np.stack([po.all_dists(po.create_lut(Xp[q], c["cents"], max(bits)), c["codes"]) for q in range(nq)])
@@ -109,6 +116,24 @@ while time.time() - t0 < budget:
                      g_lab=a.labels.reshape(nq, k), g_dis=a.distances.reshape(nq, k))
             sys.exit(1)
         n_searches += 1
+    if n_cases % 5 == 1 and N >= 64:
+        # the multi-device index with logical shards on this GPU (exchange by copies) == the same answers
+        from vaq_amd.index import VaqHipMulti
+        g = int(rng.choice([1, 2, 3, 5, 8]))
+        try:
+            m = VaqHipMulti([0] * g, bits, c["cents"], c["eig"])
+            m.set_codes(c["codes"])
+            m.set_option("queries_per_pass", int(rng.choice([0, 1, 2, 4])))
+            a = m.search(c["X"], k)
+            ties += assert_topk_matches(a.labels.reshape(nq, k), a.distances.reshape(nq, k), o_lab, o_dis, ad,
+                                        what=f"multi g={g} M={M} L={L} bits={bits} N={N} nq={nq} k={k}")
+            m.close()
+            n_searches += 1; n_multi += 1
+        except vaq_amd.VaqHipError as e:
+            if e.code != -2:
+                raise
+        except AssertionError as e:
+            print("MISMATCH (multi)", e); sys.exit(1)
     if n_cases % 3 == 0 and N >= 64 and M % 4 == 0 and sum(1 << b for b in bits) * 4 < 120000:
         # triangle-inequality form on the same rows
         T = int(rng.choice([1, 2, 7, 40, 300]))
@@ -145,5 +170,6 @@ while time.time() - t0 < budget:
                 n_searches += 1; n_ti += 1
     v.close(); n_cases += 1
 print("unsupported (EUNSUPPORTED) cases:", globals().get("n_unsupported", 0))
-print(f"fuzz ok: {n_cases} indexes, {n_searches} searches ({n_bf} in the best-first form), {ties} boundary-tie queries, "
+print(f"fuzz ok: {n_cases} indexes ({n_append} built by appends), {n_searches} searches ({n_bf} in the best-first form, "
+      f"{n_multi} on the multi-device index), {ties} boundary-tie queries, "
       f"{time.time()-t0:.0f}s, seed {seed}")

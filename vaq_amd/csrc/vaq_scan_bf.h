@@ -691,29 +691,16 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       }
     }
     __syncthreads();
-#ifdef VAQ_BF_DBG_PRINT
-    if (tid == 0 && qi == 8)
-      printf("[boot] slice %d kmin %08x bucket %d rows [%d,%d) cnt %u thr %g hdr %g\n", slice, kmin, (int)(kmin & idx_mask),
-             bs, bend, *boot_cnt, bits_to_float(*boot_thr), bits_to_float(sel.hdr[SEL_THR_D]));
-#endif
     if (tid == 0 && *boot_cnt >= (unsigned)k) {
       const unsigned tb = *boot_thr;
       if (tb < sel.hdr[SEL_THR_D]) {
         sel.hdr[SEL_THR_D] = tb;
         sel.hdr[SEL_THR_ID] = (unsigned)INT_MAX;
-#ifndef VAQ_BF_NO_BOOT_PUBLISH
-#ifdef VAQ_BF_PUB_LOOSE
-        if (multi_slice) atomicMin(&p.g_thr[qi], float_to_bits(bits_to_float(tb) * 1.5f));
-#else
         if (multi_slice) atomicMin(&p.g_thr[qi], tb);
-#endif
-#endif
       }
       // histogram over [0, H], H = the threshold every admitted row is at or below from now on
       const float H = bits_to_float(sel.hdr[SEL_THR_D]);
-#ifndef VAQ_BF_NO_HIST
       if (H > 0.0f && H < FLT_MAX) sel.hdr[BF_HDR_SCALE] = float_to_bits((float)BF_HIST_BINS / H);
-#endif
     }
     __syncthreads();
   }
@@ -748,9 +735,6 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     }
     __syncthreads();
     int n = (int)*sh_cnt;
-#ifdef VAQ_BF_DBG_PRINT
-    if (lane == 0 && qi == 8) printf("[round] slice %d wave %d n %d thr_d %g first %d\n", slice, wave, n, thr_d, (int)first_round);
-#endif
     if (n == 0) break;
     STAT_ADD(ST_FOLDS, n);
     if (n > BF_ROUND_BUCKETS) {
@@ -853,9 +837,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       const float lbv = bits_to_float(key & ~idx_mask);
       // buckets come in ascending order of their bound and thresholds only fall: nothing
       // from here on can hold an admissible row
-#ifndef VAQ_BF_DBG_NOBREAK
       if (!p.no_skip && lbv > thr_d) break;
-#endif
       STAT_ADD(ST_BUCKETS_VISITED, 1);
       const int b = (int)(key & idx_mask);
       const int bs = __builtin_amdgcn_readfirstlane(bs_raw > r0 ? bs_raw : r0);
@@ -937,18 +919,13 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     }
     // the round's buckets are done (or out of reach); empty the wave's buffers, which the next
     // round's key list borrows
-#ifndef VAQ_BF_DBG_ALLROUNDS
-    if (hi_key != 0xffffffffu)
-#endif
-    {
+    if (hi_key != 0xffffffffu) {
       while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
       while (ccnt > 0) flush();
     }
     __syncthreads();
     // Every eligible bucket was in this round and thresholds only fall: nothing is left.
-#ifndef VAQ_BF_DBG_ALLROUNDS
     if (hi_key == 0xffffffffu) break;
-#endif
     done_key = keys[n - 1];
     first_round = false;
     refresh(0);
