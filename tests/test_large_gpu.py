@@ -180,6 +180,21 @@ def test_c5_cut_64m_rows(vaqlib, oracle):
     del host
     check_forms(v, c, Xd, k, base, [(1, 1, 0, 1, 16), (2, 1, 0, 1, 16), (2, 2, 0, 1, 16), (4, 2, 0, 0, 16),
                                     (1, 2, 0, 1, 0), (4, 1, 0, 0, 16), (2, 0, 0, 1, 16), (4, 1, 1000, 1, 16)])
+    # many queries: the library switches to the best-first form (one query per workgroup, several
+    # slices per query, thresholds exchanged between them); same answers as the shared-stream forms
+    big = np.concatenate([c["X"]] * 8)[:200] + np.float32(0)
+    bigd = torch.from_numpy(np.ascontiguousarray(big)).cuda()
+    v.set_option("timing", 1)
+    lb_, db_ = search_np(v, bigd, k)
+    tb = v.last_timing()
+    v.set_option("timing", 0)
+    assert tb["best_first"] == 1 and tb["queries_per_pass"] == 1 and tb["slices"] > 1, tb
+    for j in range(200):
+        assert np.array_equal(lb_[j], base[0][j % 32]) and np.array_equal(db_[j], base[1][j % 32]), j
+    v.set_option("best_first", 0)
+    l0_, d0_ = search_np(v, bigd, k)
+    assert np.array_equal(l0_, lb_) and np.array_equal(d0_, db_)
+    v.set_option("best_first", 1)
     # the streaming measurement form (bucket_skip = 0) returns the same results
     v.set_option("bucket_skip", 0)
     for n in (2, 32):

@@ -66,6 +66,7 @@ constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bu
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
 constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short to need seeding
 constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
+constexpr int BF_STREAMED_MIN_QUERIES = 128;    // from here on the best-first form also takes streamed databases
 constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to which EA_INPLACE is chosen
 
 } // namespace
@@ -156,6 +157,15 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   // below)
   int qb = ix->opt_qb > 0 ? ix->opt_qb
                           : ((ix->layout == vaq::LAYOUT_BYTES && !resident) ? (nq >= 32 ? 4 : 2) : 1);
+  // ... but with MANY queries the best-first form (one query per workgroup, vaq_scan_bf.h) wins on
+  // streamed databases as well: each query reads only the buckets in its own reach, nearest first,
+  // and concurrent workgroups share what they read through L2 / Infinity Cache.  1B x 16 B encoded:
+  // 2048 queries 367 -> 201 ms, 10 k queries 1275 -> 807 ms; 250M, 256 queries 14.5 -> 9.7 ms; at 64
+  // queries the two are level (8.0 vs 8.3 ms at 500M) and below that the shared stream wins.
+  const bool bf_streamed = ix->opt_qb == 0 && ix->opt_bf && !resident && nq >= BF_STREAMED_MIN_QUERIES && ea == vaq::EA_QUEUE &&
+                           ix->ti_T == 0 && !ix->opt_order &&
+                           vaq::scan_bf_supported(ix->layout, ix->M, 1, ea, ix->n_buckets, ix->seq);
+  if (bf_streamed) qb = 1;
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
   // the selection state are per workgroup, the survivor queues per wave; a CU
@@ -208,8 +218,13 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   int64_t s;
   if (ix->opt_slices > 0) s = ix->opt_slices;
   else {
-    const int64_t target = (int64_t)ix->n_cu * 8;  // workgroups wanted in flight
+    // workgroups wanted in flight; the best-first form on a streamed database likes four times as
+    // many (shorter workgroups: a query's cost varies tenfold and the launch ends with the longest;
+    // 1B rows: 2048 queries x 1 / 2 / 4 / 8 / 16 slices 337 / 254 / 201 / 205 / 228 ms) and no slice
+    // of more than 2^29 rows (10 k queries x 1 / 2 / 4 slices: 887 / 807 / 823 ms)
+    const int64_t target = (int64_t)ix->n_cu * (bf_streamed ? 32 : 8);
     s = (target + nqb - 1) / nqb;
+    if (bf_streamed) s = std::max<int64_t>(s, (N + ((int64_t)1 << 29) - 1) >> 29);
     const int64_t max_s = std::max<int64_t>(1, N / MIN_SLICE_ROWS);
     s = std::min(s, max_s);
   }
