@@ -13,6 +13,7 @@ mkdir -p $out
 BARGS="--steps 20 --warmup 5 ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 bench.py $BARGS > $out/kt_bench.json 2> $out/kt.err || { tail -5 $out/kt.err; exit 1; }
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+rm -rf $out/kt  # (the raw trace of a 1B-row build is large; gpurun returns at most 64 MiB)
 echo "kernel trace done"; head -4 $out/kernel_stats.csv | cut -c1-160
 [ "$1" = "pmc" ] || exit 0
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
@@ -22,6 +23,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $pass --kernel-include-regex "scan_" --output-format csv -d $out/pmc_$name -- python3 bench.py $BARGS --no-cpu --no-recall > /dev/null 2> $out/pmc_$name.err || { echo "pmc pass failed: $pass"; tail -3 $out/pmc_$name.err; continue; }
   f=$(find $out/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 tools/pmc_summary.py $f >> $out/pmc_summary.txt
+  rm -rf $out/pmc_$name
   echo "pmc pass done: $name"
 done
 cat $out/pmc_summary.txt
