@@ -681,3 +681,31 @@ def test_query_grouping_is_invisible(vaqlib, oracle, bits):
                             what=f"qb={qb} ea={ea} slices={slices} group={group}")
     a1 = v.search(c["X"][:1], k)  # fewer queries than a pass holds
     assert np.array_equal(a1.labels, a.labels[:k])
+
+
+@pytest.mark.parametrize("k", [1, 37, 100, 160, 256, 300])
+def test_best_first_pool_tie_cut(vaqlib, oracle, k):
+    """The k-min pool of the best-first form when rows tying at the k-th distance fill it: the
+    tie is cut by label (a bisection on the labels, vaq_scan_bf.h pool_compact).  4-bit codes in
+    4 subspaces: at most 65 536 distinct rows among 300 000, so hundreds of rows share each
+    distance; k from 1 to beyond the smallest pool (k = 300: 1024 slots, the LDS-resident
+    bisection), with one and several slices per query."""
+    c = make_case(4242 + k, 16, [4] * 4, 300_000, 6, integer=True)
+    c["codes"][100_000:200_000] = c["codes"][:100_000]   # and every row at least twice
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=4, projected=True, nthreads=4)
+    ad = oracle_all_dists(oracle, c, Xp)
+    v = make_index(c)
+    v.set_option("timing", 1)
+    ran = 0
+    for slices in (1, 0, 3):
+        v.set_option("slices", slices)
+        for nw in (4, 8):
+            v.set_option("waves_per_workgroup", nw)
+            a = v.search(c["X"], k)
+            ran += v.last_timing()["best_first"]
+            ties = assert_topk_matches(a.labels.reshape(6, k), a.distances.reshape(6, k), o_lab, o_dis, ad,
+                                       what=f"k={k} slices={slices} nw={nw}")
+            assert ties >= 1 or k == 1
+    assert ran >= 2, ran
+    v.close()

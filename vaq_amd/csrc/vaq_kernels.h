@@ -84,6 +84,7 @@ struct ScanParams {
   // each query visits its own list of clusters; needs qb == 1 and ea == EA_QUEUE
   int bf_carry;           // bit-packed best-first form: 1 = the groups after the first lie in the row's last
                           //    dword, which is carried through the survivor queue
+  int bf_pool;            // best-first form: slots of the k-min pool (scan_bf_pool_range, multiple of 64)
   int bf;                 // 1: best-first form (vaq_scan_bf.h): all buckets of the slice in ascending order
                           //    of their bound, work units by ticket (needs qb == 1, ea == EA_QUEUE, no TI)
   int ti;                 // 1: TI form
@@ -152,7 +153,9 @@ int scan_wg_step_rows(int layout, int M);
 hipError_t launch_scan(const ScanParams &p, int *grid_out, hipStream_t st);
 // best-first form (vaq_scan_bf.h): is there a kernel for this plan, and its LDS bytes
 bool scan_bf_supported(int layout, int M, int qb, int ea, int n_buckets, int seq);
-size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int k, int nwaves, int n_buckets, int bf_carry);
+// `pool`: slots of the k-min pool (ScanParams::bf_pool), a multiple of 64 within scan_bf_pool_range(k)
+size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int pool, int nwaves, int n_buckets, int bf_carry);
+void scan_bf_pool_range(int k, int *lo, int *hi);
 // in_final != 0: inputs use the API's -1 / FLT_MAX convention for empty slots
 // candidate i of list l of query q sits at l*list_stride + q*query_stride + i
 // labels == nullptr: no result is written (only thr_out is wanted).

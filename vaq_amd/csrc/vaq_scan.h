@@ -288,7 +288,7 @@ __device__ __forceinline__ float sq_bound(float t) {
 #endif
 enum { ST_STEPS = 0, ST_ALIVE_A, ST_ALIVE_A2, ST_DRAINS, ST_ADMITS, ST_FOLDS, ST_CYC_TOTAL, ST_CYC_ADMIT,
        ST_CYC_DRAIN, ST_BUCKETS_TESTED, ST_BUCKETS_VISITED, ST_CYC_SETUP, ST_CYC_STEPLOAD, ST_CYC_FOLD,
-       ST_CYC_LOCKWAIT, ST_N };
+       ST_CYC_LOCKWAIT, ST_CYC_BOOT, ST_CYC_PREP, ST_CYC_FINAL, ST_CYC_SETUP_LUT, ST_N };
 
 // Shared scaffolding of the two scan kernels: LDS carve-up, threshold
 // exchange, survivor queue, admission, result write-out.

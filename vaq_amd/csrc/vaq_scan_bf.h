@@ -43,6 +43,22 @@ namespace vaq {
 #ifndef VAQ_BF_RING
 #define VAQ_BF_RING 5
 #endif
+// Issue priority of a wave (s_setprio): the per-workgroup phases in which the other waves of the
+// workgroup wait at a barrier or have nothing to do -- setup, bootstrap, ordering a round's
+// buckets, the final cut and sort -- run above the scanning waves of the other workgroups on the
+// SIMD, which hide the gap; their LDS and wave slots come free sooner.
+#ifndef VAQ_BF_PRIO
+#define VAQ_BF_PRIO 2
+#endif
+#define BF_PRIO_SERIAL() __builtin_amdgcn_s_setprio(VAQ_BF_PRIO)
+#define BF_PRIO_SCAN() __builtin_amdgcn_s_setprio(0)
+// VAQ_PHASES (diagnostic builds): cycles each wave spends in the phases of the best-first body, in
+// scalar registers (the VAQ_STATS counters cost tens of VGPRs and distort what they measure)
+#ifdef VAQ_PHASES
+#define PH_MARK(i) do { const unsigned long long ph_now = __builtin_readcyclecounter(); ph[i] += ph_now - ph_t; ph_t = ph_now; } while (0)
+#else
+#define PH_MARK(i)
+#endif
 constexpr int BF_SEG_STEPS = VAQ_BF_SEG;        // wave steps per work unit
 constexpr int BF_FLUSH_AT = VAQ_BF_FLUSH;       // candidates a wave gathers before it takes the lock
 constexpr int BF_CB_CAP = BF_FLUSH_AT - 1 + 64; // one drain appends at most 64
@@ -62,21 +78,28 @@ __host__ __device__ inline int bf_pow2(int n) {
   while (p < n) p <<= 1;
   return p;
 }
-// slots of the k-min pool (below)
+// slots of the k-min pool (below): ScanParams::bf_pool, chosen by the planner between these two so
+// that the pool never costs a resident workgroup (C2, 4 waves: 23 408 B of LDS with 512 slots is
+// 6 workgroups per CU and 1.02 ms, 22 896 B with 448 is 7 and 0.94 ms)
 #ifndef VAQ_BF_POOL
 #define VAQ_BF_POOL 512
 #endif
-__host__ __device__ inline int bf_pool_cap(int kp) { return 2 * kp < VAQ_BF_POOL ? VAQ_BF_POOL : 2 * kp; }
+#ifndef VAQ_BF_POOL_MIN
+#define VAQ_BF_POOL_MIN 320
+#endif
+__host__ __device__ inline int bf_pool_min(int kp) { return 2 * kp < VAQ_BF_POOL_MIN ? VAQ_BF_POOL_MIN : 2 * kp; }
+__host__ __device__ inline int bf_pool_max(int kp) { return 2 * kp < VAQ_BF_POOL ? VAQ_BF_POOL : 2 * kp; }
 constexpr int BF_HIST_BINS = 64;  // one per lane
+constexpr int BF_RANK_SORT_MAX = 256;  // final lists up to this long are ordered by counting, longer ones by a bitonic sort
 constexpr int BF_HDR_SCALE = 5;   // header word: float bits of bins / H, 0 = histogram off
 // code dwords a survivor carries through the queue (the rest of its row, byte codes M <= 16)
 __host__ __device__ inline int bf_queue_code_words(int M) { return M <= 16 ? M / 4 - 1 : 0; }
 // LDS of one workgroup: [LUT][k-min][sorted bucket keys, row ranges, unit prefix, ticket, gmin]
 // [per wave: survivor queue, candidate buffer]
-__host__ __device__ inline size_t bf_lds_bytes(int lut_entries, int kp, int n_buckets, int nwaves, int qcw,
+__host__ __device__ inline size_t bf_lds_bytes(int lut_entries, int pool, int n_buckets, int nwaves, int qcw,
                                                int extra_words) {
   size_t b = bf_align16((size_t)lut_entries * 4) + bf_align16((size_t)extra_words * 4);
-  b += bf_align16((size_t)SEL_HDR_WORDS * 4 + (size_t)bf_pool_cap(kp) * 8) + (size_t)BF_HIST_BINS * 4;
+  b += bf_align16((size_t)SEL_HDR_WORDS * 4 + (size_t)pool * 8) + (size_t)BF_HIST_BINS * 4;
   b += bf_align16((size_t)BF_ROUND_BUCKETS * 8 + 4 + 32 + (size_t)(1 << GMIN_MAX_BITS) * 4);
   (void)n_buckets;
   b += (size_t)nwaves * ((size_t)BF_QCAP * 4 * (2 + qcw) + (size_t)BF_CB_CAP * 8);
@@ -86,7 +109,7 @@ __host__ __device__ inline size_t bf_lds_bytes(int lut_entries, int kp, int n_bu
 // ---------------------------------------------------------------------------
 // k-min of the best-first form: an UNSORTED pool of admitted rows in LDS.
 //   header  lock, count, threshold (distance bits, label)       (SelView, vaq_scan.h)
-//   [0, cap) (distance, label) pairs, cap = bf_pool_cap(kp) >= 2 kp
+//   [0, cap) (distance, label) pairs, cap = ScanParams::bf_pool >= 2 kp
 // A row is admitted iff it is strictly below the threshold in (distance, label) order --
 // VAQ::searchHeap's rule (VAQ.cpp:1750-1753: push iff heap top > dist) with the heap top
 // replaced by any upper bound of the final k-th best, which never changes the result.
@@ -112,8 +135,8 @@ __device__ __forceinline__ int pool_count_le(const float *d, const int n, const 
 // One wave, lock held, pool holds n > k rows.  Keeps every row at or below the k-th smallest
 // distance (>= k rows; more only when rows tie at that distance) and lowers the threshold to
 // (that distance, INT_MAX).  If ties leave less than `room` free slots, the tie is cut exactly:
-// the pool is sorted by (distance, label), the k smallest stay and the threshold becomes the
-// k-th pair itself.  Returns the new count.
+// of the rows at that distance only the smallest labels stay, k rows in all, and the threshold
+// becomes the k-th (distance, label) pair itself.  Returns the new count.
 __device__ __forceinline__ int pool_compact(const SelView &sel, const int n, const int k, const int cap,
                                             const int room, const int lane) {
   unsigned lo = 0u, hi = 0x7f800000u;  // smallest t with count(bits <= t) >= k
@@ -141,36 +164,53 @@ __device__ __forceinline__ int pool_compact(const SelView &sel, const int n, con
     }
   }
   const unsigned t = lo;
-  int w = 0;
-  for (int base = 0; base < n; base += 64) {  // in-place, forwards: writes never pass the reads
-    const int i = base + lane;
-    const float di = i < n ? sel.d[i] : INFINITY;
-    const int ii = i < n ? sel.id[i] : ID_SENTINEL;
-    const bool keep = i < n && float_to_bits(di) <= t;
-    const unsigned long long m = __ballot(keep);
-    wave_lds_sync();
-    if (keep) {
-      const int pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      sel.d[pos] = di;
-      sel.id[pos] = ii;
+  // in-place, forwards: writes never pass the reads.  Keeps (distance bits, label) <= (t, tl).
+  auto keep_le = [&](const int cnt, const int tl) {
+    int w = 0;
+    for (int base = 0; base < cnt; base += 64) {
+      const int i = base + lane;
+      const float di = i < cnt ? sel.d[i] : INFINITY;
+      const int ii = i < cnt ? sel.id[i] : ID_SENTINEL;
+      const unsigned bi = float_to_bits(di);
+      const bool keep = i < cnt && (bi < t || (bi == t && ii <= tl));
+      const unsigned long long m = __ballot(keep);
+      wave_lds_sync();
+      if (keep) {
+        const int pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        sel.d[pos] = di;
+        sel.id[pos] = ii;
+      }
+      w += __popcll(m);
+      wave_lds_sync();
     }
-    w += __popcll(m);
-    wave_lds_sync();
-  }
-  float td = bits_to_float(t);
+    return w;
+  };
+  int w = keep_le(n, INT_MAX);
+  const float td = bits_to_float(t);
   int ti = INT_MAX;
-  if (w + room > cap) {  // (rows tying at the k-th distance fill the pool: cut the tie by label)
-    int P = 2;
-    while (P < w) P <<= 1;
-    for (int i = w + lane; i < P; i += 64) {
-      sel.d[i] = INFINITY;
-      sel.id[i] = ID_SENTINEL;
+  if (w > k && w + room > cap) {
+    // Rows tying at the k-th distance fill the pool: cut the tie by label.  The rows below t
+    // stay; of the rows at t the (k - below) smallest labels do -- the same bisection, on the
+    // labels (distinct, >= 0), so the pool needs no sorting and no power-of-two capacity.
+    int below = 0;
+    for (int base = 0; base < w; base += 64) {
+      const int i = base + lane;
+      below += __popcll(__ballot(i < w && float_to_bits(sel.d[i]) < t));
     }
-    wave_lds_sync();
-    bitonic_sort<false>(sel.d, sel.id, P, lane, 64);
-    w = k;
-    td = sel.d[k - 1];
-    ti = sel.id[k - 1];
+    const int need = k - below;  // >= 1: fewer than k rows lie below the k-th smallest distance
+    unsigned llo = 0u, lhi = 0x7fffffffu;
+    while (llo < lhi) {
+      const unsigned mid = llo + ((lhi - llo) >> 1);
+      int c = 0;
+      for (int base = 0; base < w; base += 64) {
+        const int i = base + lane;
+        c += __popcll(__ballot(i < w && float_to_bits(sel.d[i]) == t && (unsigned)sel.id[i] <= mid));
+      }
+      if (c >= need) lhi = mid;
+      else llo = mid + 1u;
+    }
+    ti = (int)llo;
+    w = keep_le(w, ti);  // == k
   }
   const float od = bits_to_float(sel.hdr[SEL_THR_D]);
   const int oi = (int)sel.hdr[SEL_THR_ID];
@@ -386,7 +426,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   size_t off = bf_align16((size_t)lut_entries * 4);
   unsigned *pol_words = reinterpret_cast<unsigned *>(smem + off);
   off += bf_align16((size_t)Pol::LDS_WORDS * 4);
-  const int cap = bf_pool_cap(kp);
+  const int cap = p.bf_pool;
   const SelView sel = sel_view(smem + off, cap, 0);
   off += bf_align16((size_t)SEL_HDR_WORDS * 4 + (size_t)cap * 8);
   unsigned *hist = reinterpret_cast<unsigned *>(smem + off);  // [64] admitted rows per distance bin
@@ -416,9 +456,15 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
   // ---- setup ----
+#ifdef VAQ_PHASES
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph_t = __builtin_readcyclecounter();
+#endif
+  BF_PRIO_SERIAL();
   const float *__restrict__ glut = p.lut + (size_t)qi * p.lut_floats;
   const int *__restrict__ bstart = p.bucket_start;
   const int nwaves = nthreads >> 6;
+  const int bs_first = tid < K0 ? bstart[tid] : 0, be_first = tid < K0 ? bstart[tid + 1] : 0;
   for (int e = tid; e < lut_entries; e += nthreads) lut[e] = glut[e];
   Pol pol;
   pol.init(p, lut, pol_words, tid, nthreads);  // (its LDS tables are complete after the barriers below)
@@ -447,29 +493,45 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     int off1, ncent1;
     Pol::second_table(p, off1, ncent1);
     const int w = 31 - __builtin_clz((unsigned)ncent1) - bt;  // log2 of the group size
-    for (int e = tid; e < ncent1; e += nthreads) atomicMin(&gmin[e >> w], float_to_bits(glut[off1 + e]));
+    // (a wave's 64 consecutive entries span whole groups or lie within one: reduce across the
+    //  lanes of a group first, one LDS atomic per group and wave instead of one per entry)
+    const int seg = w < 6 ? 1 << w : 64;
+    for (int e0 = tid - lane; e0 < ncent1; e0 += nthreads) {
+      const int e = e0 + lane;
+      unsigned v = e < ncent1 ? float_to_bits(lut[off1 + e]) : 0x7f800000u;
+      for (int o = 1; o < seg; o <<= 1) {
+        const unsigned x = (unsigned)__shfl_xor((int)v, o);
+        v = x < v ? x : v;
+      }
+      if ((lane & (seg - 1)) == 0 && e < ncent1) atomicMin(&gmin[e >> w], v);
+    }
   }
   __syncthreads();
+#ifdef VAQ_STATS
+  cx.st[ST_CYC_SETUP_LUT] = __builtin_readcyclecounter() - t_begin;
+#endif
+  PH_MARK(0);
   // One packed word per bucket: lower bound of its row sums (low bits cut: still a lower bound) |
   // bucket -- unique.  Empty buckets and NaN tables get the largest keys and are never eligible.
   const unsigned empty_key = ~idx_mask;
-  auto bucket_key = [&](const int b) -> unsigned {
-    const int s0 = bstart[b] > r0 ? bstart[b] : r0;
-    const int e0 = bstart[b + 1] < r1 ? bstart[b + 1] : r1;
+  auto bucket_key_of = [&](const int b, const int bs_raw, const int be_raw) -> unsigned {
+    const int s0 = bs_raw > r0 ? bs_raw : r0;
+    const int e0 = be_raw < r1 ? be_raw : r1;
     if (e0 <= s0) return empty_key | (unsigned)b;
     float m;
     if (bt > 0) {
-      m = glut[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
+      m = lut[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
     } else {
       m = INFINITY;
       for (int c = b << bshift; c < ((b + 1) << bshift); c++) {
-        const float x = glut[c];
+        const float x = lut[c];
         m = x < m ? x : m;
       }
     }
     if (!(m == m)) return empty_key | (unsigned)b;
     return (float_to_bits(m) & ~idx_mask) | (unsigned)b;  // m >= 0: bit order == value order
   };
+  auto bucket_key = [&](const int b) -> unsigned { return bucket_key_of(b, bstart[b], bstart[b + 1]); };
   auto units_of = [&](const unsigned key) -> int {
     const int b = (int)(key & idx_mask);
     const int s0 = bstart[b] > r0 ? bstart[b] : r0;
@@ -480,11 +542,22 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // picked its buckets; a thread only ever reads back the entries it wrote
   unsigned *kall = kuns + BF_ROUND_BUCKETS;  // [K0]
   unsigned km0 = 0xffffffffu;
+  {
+    // (the row range of the thread's next bucket is fetched while this one's key is formed, and
+    //  the first one before the tables arrive: one memory round trip is exposed, not one per key)
+    int bs_n = bs_first, be_n = be_first;
 #pragma unroll 1
-  for (int b = tid; b < K0; b += nthreads) {
-    const unsigned key = bucket_key(b);
-    kall[b] = key;
-    km0 = key < km0 ? key : km0;
+    for (int b = tid; b < K0; b += nthreads) {
+      const int bs_c = bs_n, be_c = be_n;
+      const int bn = b + nthreads;
+      if (bn < K0) {
+        bs_n = bstart[bn];
+        be_n = bstart[bn + 1];
+      }
+      const unsigned key = bucket_key_of(b, bs_c, be_c);
+      kall[b] = key;
+      km0 = key < km0 ? key : km0;
+    }
   }
   {  // the nearest bucket (smallest key)
     unsigned km = km0;
@@ -499,6 +572,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
 #ifdef VAQ_STATS
   cx.st[ST_CYC_SETUP] = __builtin_readcyclecounter() - t_begin;
 #endif
+  PH_MARK(1);
   // ---- per-wave state ----
   float thr_d = FLT_MAX;  // wave-uniform cached copy of the threshold distance (never below the exact one)
   int qcnt = 0, ccnt = 0, stepno = 0;
@@ -536,6 +610,11 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     STAT_T0(t_fl);
     STAT_ADD(ST_ADMITS, 1);
     const int rid = (cand && perm) ? (int)perm[srow] : srow;  // labels are ORIGINAL rows: ties break by them
+    // Wait for that load HERE.  Left to the compiler, its wait lands after the lock's spin loop, and
+    // the wait-count bookkeeping of every block this rarely taken path rejoins degrades to "all
+    // loads" (seen in the ISA: s_waitcnt vmcnt(0) in front of each step of the scan loop below,
+    // i.e. no prefetch; with this line the steps wait for vmcnt(BF_RING - 1)).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt, lgkmcnt untouched
     STAT_T0(t_lk);
     sel_lock(sel, lane);
     STAT_T1(ST_CYC_LOCKWAIT, t_lk);
@@ -649,6 +728,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // distance, i.e. a valid admission threshold (with label INT_MAX: rows AT that distance stay
   // admissible).  It also bounds which buckets can matter at all (below).
   const unsigned kmin = *sh_min;
+  STAT_T0(t_boot);
   if (BF_BOOT_STEPS > 0 && !p.no_skip && (kmin & empty_key) != empty_key) {
     const int bb = (int)(kmin & idx_mask);
     const int bs = bstart[bb] > r0 ? bstart[bb] : r0;
@@ -705,12 +785,17 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     __syncthreads();
   }
   refresh(0);  // the bootstrapped / seeded / already published threshold, before the first bound is tested
+  STAT_T1(ST_CYC_BOOT, t_boot);
+  PH_MARK(2);
   // ---- rounds: the eligible buckets (bound not above the threshold, not done yet), nearest first,
   //      at most BF_ROUND_BUCKETS per round; thresholds fall while a round runs, so a second round
   //      is rarely anything but the check that nothing is left ----
   bool first_round = true;
   unsigned done_key = 0u;  // buckets with keys <= done_key are finished (after the first round)
   for (;;) {
+    BF_PRIO_SERIAL();
+    PH_MARK(5);
+    STAT_T0(t_prep);
     if (tid == 0) *sh_cnt = 0u;
     __syncthreads();
     // the round's threshold must be the SAME for every thread (the bisection below is a workgroup-
@@ -806,6 +891,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       }
     }
     __syncthreads();
+    STAT_T1(ST_CYC_PREP, t_prep);
+    PH_MARK(3);
+    BF_PRIO_SCAN();
     const int total_units = cum[n];
     // window of the unit prefix in registers: lane j holds cum[wbase + j + 1]
     int wbase = 0;
@@ -898,25 +986,34 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
         }
       };
 
+      // BF_RING code items in flight per wave.  Every path through the loop issues the SAME number
+      // of loads (one past the unit's end re-reads its last item: a cache hit): a load that is
+      // issued on some paths only leaves the compiler no count it can wait for but zero, and every
+      // step then waits for the load issued just before it -- no prefetch at all (seen in the ISA:
+      // s_waitcnt vmcnt(0) at each step; with uniform counts it is vmcnt(BF_RING - 1)).
       Item ring[BF_RING];
+      const int last = nst - 1;  // (nst >= 1: a unit has rows)
   #pragma unroll
-      for (int u = 0; u < BF_RING; u++)
-        if (u < nst) Pol::load(ring[u], codes, base0 + u * WSTEP, lane);
-      for (int st = 0; st < nst; st += BF_RING) {
+      for (int u = 0; u < BF_RING; u++) Pol::load(ring[u], codes, base0 + (u < last ? u : last) * WSTEP, lane);
+      int st = 0;
+      for (; st + BF_RING < nst; st += BF_RING) {
   #pragma unroll
         for (int u = 0; u < BF_RING; u++) {
-          if (st + u < nst) {
-            step(ring[u], st + u);
-            if (st + u + BF_RING < nst) Pol::load(ring[u], codes, base0 + (st + u + BF_RING) * WSTEP, lane);
-          }
+          step(ring[u], st + u);
+          const int nx = st + u + BF_RING;
+          Pol::load(ring[u], codes, base0 + (nx < last ? nx : last) * WSTEP, lane);
         }
       }
+  #pragma unroll
+      for (int u = 0; u < BF_RING; u++)
+        if (st + u < nst) step(ring[u], st + u);
       t = t_next;
       i = i_n;
       key = key_n;
       bs_raw = bs_n;
       be_raw = be_n;
     }
+    PH_MARK(4);
     // the round's buckets are done (or out of reach); empty the wave's buffers, which the next
     // round's key list borrows
     if (hi_key != 0xffffffffu) {
@@ -930,12 +1027,15 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     first_round = false;
     refresh(0);
   }
+  BF_PRIO_SERIAL();
+  PH_MARK(5);
   STAT_T0(t_tail);
   while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
   while (ccnt > 0) flush();
 
   // ---- results: wave 0 cuts the pool to the k best and sorts them ----
   __syncthreads();
+  PH_MARK(6);
 #ifdef VAQ_STATS
   cx.st[ST_CYC_STEPLOAD] = __builtin_readcyclecounter() - t_tail;  // (tail: last drains / flushes + waiting for the other waves)
   cx.st[ST_CYC_TOTAL] = __builtin_readcyclecounter() - t_begin;
@@ -943,37 +1043,69 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     for (int i = 0; i < ST_N; i++) atomicAdd(&p.stats[i], cx.st[i]);
 #endif
   if (wave == 0) {
+    STAT_T0(t_fin);
     int n = (int)sel.hdr[SEL_NCAND];
-    if (n > k) n = pool_compact(sel, n, k, cap, 0, lane);  // rows at or below the k-th distance
-    int P = 2;
-    while (P < n) P <<= 1;
-    const int pad_to = P > kp ? P : kp;
-    for (int i = n + lane; i < pad_to; i += 64) {
-      sel.d[i] = INFINITY;
-      sel.id[i] = ID_SENTINEL;
-    }
-    wave_lds_sync();
-    bitonic_sort<false>(sel.d, sel.id, P, lane, 64);  // ascending by (distance, label)
-    const int nbest = n < k ? n : k;
-    if (p.final_labels) {
-      // one slice per query: this list IS the result, in the API's format (heap_reorder's:
-      // ascending, empty slots -1 / FLT_MAX, utils/Heap.hpp:322-349)
-      const size_t o = (size_t)qi * k;
-      for (int i = lane; i < k; i += 64) {
-        const int id = sel.id[i];
+    PH_MARK(8);
+    if (n > k) n = pool_compact(sel, n, k, cap, cap, lane);  // exactly the k best (ties cut by label)
+    PH_MARK(9);
+    // result slot i: the API's format when this list IS the result (one slice per query;
+    // heap_reorder's: ascending, empty slots -1 / FLT_MAX, utils/Heap.hpp:322-349), else a
+    // partial list for the merge
+    const size_t o = p.final_labels ? (size_t)qi * k : ((size_t)qi * p.n_slices + slice) * k;
+    auto emit = [&](const int i, const float d, const int id) {
+      if (p.final_labels) {
         const bool ok = id != ID_SENTINEL;
         p.final_labels[o + i] = ok ? (int32_t)(id + p.id_base) : -1;
-        p.final_dist[o + i] = ok ? sel.d[i] : FLT_MAX;
+        p.final_dist[o + i] = ok ? d : FLT_MAX;
+      } else {
+        p.part_d[o + i] = d;
+        p.part_id[o + i] = id;
       }
+    };
+    if (n <= BF_RANK_SORT_MAX) {
+      // Few rows: each lane counts the rows below its own -- (distance bits, label) compared as
+      // one 64-bit key, distinct because labels are -- and writes its row at that position.
+      // The other rows are broadcast reads of LDS, independent of each other: no chain of
+      // dependent compare-exchange stages as in a sorting network (28 for 128 rows).
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < n;
+        const float di = valid ? sel.d[i] : INFINITY;
+        const int ii = valid ? sel.id[i] : ID_SENTINEL;
+        const unsigned long long ki = ((unsigned long long)float_to_bits(di) << 32) | (unsigned)ii;
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < n; j++) {
+          const unsigned long long kj = ((unsigned long long)float_to_bits(sel.d[j]) << 32) | (unsigned)sel.id[j];
+          rank += kj < ki ? 1 : 0;
+        }
+        if (valid) emit(rank, di, ii);
+      }
+      for (int i = n + lane; i < k; i += 64) emit(i, INFINITY, ID_SENTINEL);
     } else {
-      const size_t o = ((size_t)qi * p.n_slices + slice) * k;
-      for (int i = lane; i < k; i += 64) {
-        p.part_d[o + i] = sel.d[i];
-        p.part_id[o + i] = sel.id[i];
+      int P = 2;
+      while (P < n) P <<= 1;
+      const int pad_to = P > kp ? P : kp;
+      for (int i = n + lane; i < pad_to; i += 64) {
+        sel.d[i] = INFINITY;
+        sel.id[i] = ID_SENTINEL;
       }
-      if (lane == 0) p.part_cnt[(size_t)qi * p.n_slices + slice] = nbest;
+      wave_lds_sync();
+      bitonic_sort<false>(sel.d, sel.id, P, lane, 64);  // ascending by (distance, label)
+      for (int i = lane; i < k; i += 64) emit(i, sel.d[i], sel.id[i]);
     }
+    if (!p.final_labels && lane == 0) p.part_cnt[(size_t)qi * p.n_slices + slice] = n < k ? n : k;
+#ifdef VAQ_STATS
+    if (p.stats && lane == 0) atomicAdd(&p.stats[ST_CYC_FINAL], __builtin_readcyclecounter() - t_fin);
+#endif
   }
+#ifdef VAQ_PHASES
+  PH_MARK(7);
+  if (p.stats && lane == 0 && (blockIdx.x & 63) == 0) {  // (a sample: same-address atomics from every wave would be the slowest thing in the kernel)
+    for (int i = 0; i < 10; i++) atomicAdd(&p.stats[i], ph[i]);
+    atomicAdd(&p.stats[10], 1ull);
+  }
+#endif
 }
 
 // bytes of LDS of the byte-code best-first kernel and its launch (vaq_scan_bf.hip)

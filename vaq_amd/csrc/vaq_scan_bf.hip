@@ -23,10 +23,15 @@ int scan_bf_queue_words(int layout, int M, int bf_carry) {
   return layout == LAYOUT_BYTES ? bf_queue_code_words(M) : (bf_carry ? 1 : 0);
 }
 
-size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int k, int nwaves, int n_buckets, int bf_carry) {
+void scan_bf_pool_range(int k, int *lo, int *hi) {
   int kp = 1;
   while (kp < k) kp <<= 1;
-  return bf_lds_bytes(layout == LAYOUT_BYTES ? M * 256 : lut_entries, kp, n_buckets, nwaves,
+  *lo = bf_pool_min(kp);
+  *hi = bf_pool_max(kp);
+}
+
+size_t scan_bf_lds_bytes(int layout, int M, int lut_entries, int pool, int nwaves, int n_buckets, int bf_carry) {
+  return bf_lds_bytes(layout == LAYOUT_BYTES ? M * 256 : lut_entries, pool, n_buckets, nwaves,
                       scan_bf_queue_words(layout, M, bf_carry), layout == LAYOUT_BYTES ? 0 : VAQ_BF_MAX_SUBS);
 }
 
@@ -52,7 +57,10 @@ hipError_t launch_scan_bf(const ScanParams &p, int grid, hipStream_t st) {
     return hipErrorInvalidValue;
   if (p.layout == LAYOUT_BITS && (p.lds_subs != p.M || p.lut_lds_entries != p.lut_floats))
     return hipErrorInvalidValue;  // every table must sit in LDS
-  const size_t lds = scan_bf_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.k, p.nwaves, p.n_buckets, p.bf_carry);
+  int pool_lo, pool_hi;
+  scan_bf_pool_range(p.k, &pool_lo, &pool_hi);
+  if (p.bf_pool < pool_lo || p.bf_pool > pool_hi || p.bf_pool % 64 != 0) return hipErrorInvalidValue;
+  const size_t lds = scan_bf_lds_bytes(p.layout, p.M, p.lut_lds_entries, p.bf_pool, p.nwaves, p.n_buckets, p.bf_carry);
   if (p.layout == LAYOUT_BYTES) {
     switch (p.M) {
     case 8:  VAQ_BF_M(8)

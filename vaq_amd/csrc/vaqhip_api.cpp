@@ -60,6 +60,7 @@ struct DevBuf {
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
+constexpr size_t LDS_GRANULE = 1280;           // allocation unit assumed when counting resident workgroups
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
@@ -135,6 +136,7 @@ struct Plan {
   bool ordered;  // slices dispatched best-first per query batch
   bool bf = false;  // best-first scan form (vaq_scan_bf.h)
   int bf_carry = 0;
+  int bf_pool = 0;
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -265,24 +267,35 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   if (ix->opt_bf && ea == vaq::EA_QUEUE && qb == 1 && !pl->ordered && subs == ix->M &&
       vaq::scan_bf_supported(ix->layout, ix->M, qb, ea, ix->n_buckets, ix->seq) && ix->n_buckets >= 16 &&
       pl->slice_rows >= 8 * (N / ix->n_buckets + 1)) {
-    int bnw = 0, bscore = 0;
+    int bnw = 0, bscore = 0, bpool = 0;
     size_t blds = 0;
+    int pool_lo, pool_hi;
+    vaq::scan_bf_pool_range(k, &pool_lo, &pool_hi);
     // bit-packed rows: when every field after the first group lies in the last dword, it is queued
     const int carry = (ix->layout == vaq::LAYOUT_BITS && ix->M > 4 && ix->sub[4].word == ix->W - 1) ? 1 : 0;
     for (int nw : {4, 8, 16}) {
       if (ix->opt_nwaves > 0 && nw != ix->opt_nwaves) continue;
-      const size_t lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, k, nw, ix->n_buckets, carry);
+      size_t lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, pool_lo, nw, ix->n_buckets, carry);
       if (lds > LDS_LIMIT) continue;
       const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
+      // the largest k-min pool that keeps that many workgroups resident (LDS is handed out in
+      // LDS_GRANULE pieces; at 72 VGPRs a SIMD holds 7 waves, so 4-wave workgroups stop at 7)
+      const size_t budget = LDS_LIMIT / (size_t)std::min(wgs, std::max(1, 28 / nw)) / LDS_GRANULE * LDS_GRANULE;
+      int pool = pool_lo;
+      while (pool + 64 <= pool_hi &&
+             vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, pool + 64, nw, ix->n_buckets, carry) <= budget)
+        pool += 64;
+      lds = vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, pool, nw, ix->n_buckets, carry);
       // small workgroups win here even at lower residency: setup, bootstrap and the final sort
       // are per workgroup and leave its other waves idle (C2: 4 waves x 6 workgroups per CU
       // 1.02 ms, 8 x 4 1.15 ms, 16 x 2 1.8 ms)
       const int score = nw == 4 ? wgs * nw * 10 : nw == 8 ? wgs * nw * 7 : wgs * nw * 4;
-      if (score > bscore) { bscore = score; bnw = nw; blds = lds; }
+      if (score > bscore) { bscore = score; bnw = nw; blds = lds; bpool = pool; }
     }
     if (bnw) {
       pl->bf = true;
       pl->bf_carry = carry;
+      pl->bf_pool = bpool;
       pl->nwaves = bnw;
       pl->lds = blds;
     }
@@ -452,12 +465,13 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.n_hot = 0;
     sp.bf = 0;
     sp.bf_carry = 0;
+    sp.bf_pool = 0;
     sp.no_skip = ix->opt_no_skip;
     sp.stats = nullptr;
-#ifdef VAQ_STATS
+#if defined(VAQ_STATS) || defined(VAQ_PHASES)
     static unsigned long long *d_stats = nullptr;
-    if (!d_stats) HIP_TRY(hipMalloc(&d_stats, 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
+    if (!d_stats) HIP_TRY(hipMalloc(&d_stats, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 24 * sizeof(unsigned long long), st));
     sp.stats = d_stats;
 #endif
     sp.lut = ix->w_lut.as<float>();
@@ -586,19 +600,33 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                 pl.slice_rows >= 8 * (ix->N / sp.n_buckets + 1)) ? ix->opt_hot : 0;
     sp.bf = pl.bf ? 1 : 0;
     sp.bf_carry = pl.bf_carry;
+    sp.bf_pool = pl.bf_pool;
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+#ifdef VAQ_PHASES
+    if (pl.bf) {
+      unsigned long long h[11];
+      HIP_TRY(hipMemcpyAsync(h, sp.stats, sizeof h, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const double w = (double)std::max<unsigned long long>(h[10], 1);  // reporting waves
+      std::fprintf(stderr,
+                   "[VAQ_PHASES] cycles per wave: tables %.0f keys %.0f bootstrap %.0f round prep %.0f scan %.0f "
+                   "round end %.0f tail %.0f final (wave 0 works): read count %.0f cut %.0f order + write %.0f | sum %.0f\n",
+                   h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[8] / w, h[9] / w, h[7] / w,
+                   (h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6] + h[7] + h[8] + h[9]) / w);
+    }
+#endif
 #ifdef VAQ_STATS
     {
-      unsigned long long h[16];
+      unsigned long long h[24];
       HIP_TRY(hipMemcpyAsync(h, sp.stats, sizeof h, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       const double w = (double)grid * sp.nwaves;
       std::fprintf(stderr,
                    "[VAQ_STATS] per wave: steps %.1f alive_A %.1f alive_A2 %.1f drains %.2f admits %.2f folds %.2f "
                    "buckets tested %.1f visited %.1f | cycles total %.0f setup %.0f stepload-wait %.0f admit %.0f "
-                   "(fold %.0f lock-wait %.0f) drain %.0f\n",
+                   "(fold %.0f lock-wait %.0f) drain %.0f | best-first: bootstrap %.0f round prep %.0f final (wave 0) %.0f setup up to the tables %.0f\n",
                    h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[9] / w, h[10] / w, h[6] / w, h[11] / w,
-                   h[12] / w, h[7] / w, h[13] / w, h[14] / w, h[8] / w);
+                   h[12] / w, h[7] / w, h[13] / w, h[14] / w, h[8] / w, h[15] / w, h[16] / w, (double)h[17] / grid, h[18] / w);
     }
 #endif
     if (timing) HIP_TRY(hipEventRecord(ev[4], st));
