@@ -64,6 +64,7 @@ constexpr size_t LDS_GRANULE = 1280;           // allocation unit assumed when c
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
+constexpr int64_t BUCKET_MIN_ROWS_10 = 1900;   // ... before it takes a tenth key bit
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
 constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short to need seeding
 constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
@@ -811,19 +812,29 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
     K0 = ix->ti_T;
   } else {
     // bucket key = the top bits of the first code, continued -- when the whole first code is
-    // used up -- by up to 4 top bits of the second: as many key bits as keep ~1000 rows per
+    // used up -- by up to 4 top bits of the second: as many key bits as keep ~900 rows per
     // bucket on average, at most 10 (measured on 250M rows x 16 B: 10 bits beat 8, 11 and 12
-    // for 2, 32 and 256 queries; the option accepts up to 12)
+    // for 2, 32 and 256 queries; the option accepts up to 12); a tenth bit from the second code
+    // wants ~1900 rows per bucket (8 B rows, 10 k queries, best-first form: 1M rows 0.86 / 0.75 /
+    // 0.83 ms with 8 / 9 / 10 bits, 2M 1.41 / 1.11 / 1.09, 8M 4.98 / 3.36 / 2.96), one from the
+    // first code does not (12-bit first code, 1M rows: 1.54 ms with 10 bits, 1.83 with 9)
     int want = 4;
     while (want < 10 && ((int64_t)2 << want) * BUCKET_MIN_ROWS <= std::max<int64_t>(N, 1)) want++;
     if (ix->opt_bucket_bits > 0) want = ix->opt_bucket_bits;
     const int kb = std::min(want, ix->bits[0]);
     shift = ix->bits[0] - kb;
-    // (continuing into the second code pays on large databases -- 250M rows, 32 queries: 4.0 vs
-    //  5.3 ms -- and costs on small ones, where the per-bucket bookkeeping outweighs it: 1M rows,
-    //  10 bits: 2.0 vs 1.45 ms; an explicit "bucket_bits" option is obeyed as given)
-    if (shift == 0 && ix->M > 1 && (N >= ((int64_t)1 << 24) || ix->opt_bucket_bits > 0))
-      bt = std::min(std::min(want - kb, 4), ix->bits[1]);
+    // Continuing into the second code: always where the best-first form will scan the rows (its
+    // per-bucket bookkeeping is a key in LDS), else only on large databases -- 250M rows, 32
+    // queries: 4.0 vs 5.3 ms, but 1M rows, 10 bits, shared-stream form: 2.0 vs 1.45 ms; an
+    // explicit "bucket_bits" option is obeyed as given
+    if (shift == 0 && ix->M > 1) {
+      int want_c = want;  // (a tenth bit taken from the SECOND code wants more rows per bucket)
+      if (want_c == 10 && kb < 10 && ix->opt_bucket_bits <= 0 && N < (int64_t)1024 * BUCKET_MIN_ROWS_10) want_c = 9;
+      const int cont = std::min(std::min(want_c - kb, 4), ix->bits[1]);
+      const bool bf_form = ix->opt_bf && cont > 0 &&
+                           vaq::scan_bf_supported(ix->layout, ix->M, 1, vaq::EA_QUEUE, 1 << (kb + cont), ix->seq);
+      if (N >= ((int64_t)1 << 24) || ix->opt_bucket_bits > 0 || bf_form) bt = std::max(cont, 0);
+    }
     K0 = 1 << (kb + bt);
   }
   HIP_TRY(ix->d_bstart.ensure((size_t)(K0 + 1) * sizeof(int)));
