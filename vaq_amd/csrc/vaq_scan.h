@@ -215,6 +215,9 @@ constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 #endif
 // (not the in-place form: it is HBM-bound with waves to spare and only pays for the spills)
 #define VAQ_SCAN_SGPRS __attribute__((amdgpu_num_sgpr(VAQ_SCAN_SGPR_CAP)))
+#ifndef VAQ_STREAM_RING
+#define VAQ_STREAM_RING 3  // code items in flight per wave of the streaming (every-bucket) form
+#endif
 #ifndef VAQ_PREFETCH
 #define VAQ_PREFETCH 2
 #endif
@@ -666,6 +669,9 @@ template <int QB, bool SQ> struct ScanCtx {
     st[ST_ADMITS]++;
 #endif
     const int rid = (ok && survives(dist) && perm) ? (int)perm[srow] : srow;
+    // (wait for that load here: left to the compiler its wait lands after the lock's spin loop,
+    //  and the scan loop this rare path rejoins loses its exact load counts -- vaq_scan_bf.h flush())
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt, lgkmcnt untouched
 #pragma unroll
     for (int q = 0; q < QB; q++) {
       if (__ballot(ok && !(dist[q] > thr_d[q])) == 0ull) continue;
@@ -1074,32 +1080,8 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
             STAT_ADD(ST_BUCKETS_VISITED, 1);
             const int base0 = pos & ~(WSTEP - 1);
             const int nst = (be - base0 + WSTEP - 1) / WSTEP;  // wave steps in this bucket segment
-            Item pf[PREFETCH];
-            float xpf[PREFETCH];  // TI: centre distance of each step's first row (wave-uniform)
-#pragma unroll
-            for (int i = 0; i < PREFETCH; i++)
-              if (i < nst) {
-                pf[i].load(p.codes, (int64_t)((base0 + i * WSTEP) / Item::ROWS) + lane);
-                if (TI) xpf[i] = xcc[i == 0 ? pos : base0 + i * WSTEP];
-              }
-            for (int t = 0; t < nst; t++) {
-              STAT_T0(t_ld);
-              const Item cur = pf[0];
-#ifdef VAQ_STATS
-              asm volatile("" ::"v"(cur.w[0].x));  // the wait for this step's item lands here
-              STAT_T1(ST_CYC_STEPLOAD, t_ld);
-#endif
-              const float xcur =
-                  TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
-#pragma unroll
-              for (int i = 0; i + 1 < PREFETCH; i++) {
-                pf[i] = pf[i + 1];
-                if (TI) xpf[i] = xpf[i + 1];
-              }
-              if (t + PREFETCH < nst) {
-                pf[PREFETCH - 1].load(p.codes, (int64_t)((base0 + (t + PREFETCH) * WSTEP) / Item::ROWS) + lane);
-                if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * WSTEP];
-              }
+            // one wave step: the item's rows against the query batch; false = the unit is over (TI)
+            auto do_step = [&](const Item &cur, const float xcur, const int t) -> bool {
               const int base = base0 + t * WSTEP;
               STAT_ADD(ST_STEPS, 1);
               cx.refresh(stepno++);
@@ -1108,7 +1090,7 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                 // the bound qc - xcc only grows from here on: once it clears the threshold the
                 // rest of the unit cannot hold an admissible row
                 const float bound = (qc - xcur) - TI_SLACK * (qc + xcur);
-                if (bound >= cx.thr_s[0]) break;
+                if (bound >= cx.thr_s[0]) return false;
               }
               const int row0 = base + lane * Item::ROWS;
               // A: dism = l0; dism += l1, every row of the item, all lanes
@@ -1152,6 +1134,59 @@ __device__ __forceinline__ void scan_bytes_body(const ScanParams &p) {
                   for (int i = 0; i < WPR; i++) cw[i] = cur.word(r, i);
                   finish(cw, part[r], row0 + r, live);
                 }
+              }
+              return true;
+            };
+            if constexpr (STREAM && !TI && VAQ_STREAM_RING > 0) {
+              // VAQ_STREAM_RING items in flight per wave in registers of their own, every path
+              // issuing the same number of loads (a load past the segment's end re-reads its last
+              // item): the steps wait for vmcnt(VAQ_STREAM_RING - 1), not for every load (the
+              // two-deep copy loop below has one load in flight while a step computes)
+              Item ring[VAQ_STREAM_RING > 0 ? VAQ_STREAM_RING : 1];
+              const int last = nst - 1;
+#pragma unroll
+              for (int u = 0; u < VAQ_STREAM_RING; u++)
+                ring[u].load(p.codes, (int64_t)((base0 + (u < last ? u : last) * WSTEP) / Item::ROWS) + lane);
+              int t = 0;
+              for (; t + VAQ_STREAM_RING < nst; t += VAQ_STREAM_RING) {
+#pragma unroll
+                for (int u = 0; u < VAQ_STREAM_RING; u++) {
+                  do_step(ring[u], 0.0f, t + u);
+                  const int nx = t + u + VAQ_STREAM_RING;
+                  ring[u].load(p.codes, (int64_t)((base0 + (nx < last ? nx : last) * WSTEP) / Item::ROWS) + lane);
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < VAQ_STREAM_RING; u++)
+                if (t + u < nst) do_step(ring[u], 0.0f, t + u);
+            } else {
+              Item pf[PREFETCH];
+              float xpf[PREFETCH];  // TI: centre distance of each step's first row (wave-uniform)
+#pragma unroll
+              for (int i = 0; i < PREFETCH; i++)
+                if (i < nst) {
+                  pf[i].load(p.codes, (int64_t)((base0 + i * WSTEP) / Item::ROWS) + lane);
+                  if (TI) xpf[i] = xcc[i == 0 ? pos : base0 + i * WSTEP];
+                }
+              for (int t = 0; t < nst; t++) {
+                STAT_T0(t_ld);
+                const Item cur = pf[0];
+#ifdef VAQ_STATS
+                asm volatile("" ::"v"(cur.w[0].x));  // the wait for this step's item lands here
+                STAT_T1(ST_CYC_STEPLOAD, t_ld);
+#endif
+                const float xcur =
+                    TI ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(xpf[0]))) : 0.0f;
+#pragma unroll
+                for (int i = 0; i + 1 < PREFETCH; i++) {
+                  pf[i] = pf[i + 1];
+                  if (TI) xpf[i] = xpf[i + 1];
+                }
+                if (t + PREFETCH < nst) {
+                  pf[PREFETCH - 1].load(p.codes, (int64_t)((base0 + (t + PREFETCH) * WSTEP) / Item::ROWS) + lane);
+                  if (TI) xpf[PREFETCH - 1] = xcc[base0 + (t + PREFETCH) * WSTEP];
+                }
+                if (!do_step(cur, xcur, t)) break;
               }
             }
           }

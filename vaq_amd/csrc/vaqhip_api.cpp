@@ -194,7 +194,12 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
         const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(wave_cap / nw));
         // 16 waves share one admission lock and one ticket: measured much slower than 8 at equal
         // residency (C3: 5.8 vs 3.1 ms), so they must buy > 1.5x the waves to be chosen
-        const int score = nw == 16 ? (wgs * nw * 2) / 3 : wgs * nw;
+        // (not when every bucket is streamed in place, where the lock is taken for admitted rows
+        //  only and the waves just keep loads in flight: 1B rows, 16 waves x 2 workgroups per CU
+        //  2.78 ms, 8 x 3 2.90 ms; with bucket skipping on it is the other way round, 250M rows x 2
+        //  queries 0.27 vs 0.23 ms)
+        const bool streaming = ea == vaq::EA_INPLACE && ix->opt_no_skip;
+        const int score = (nw == 16 && !streaming) ? (wgs * nw * 2) / 3 : wgs * nw;
         if (score > best_waves) { best_waves = score; best_nw = nw; }
       }
       if (best_nw) break;
