@@ -32,7 +32,7 @@
 namespace vaq {
 
 #ifndef VAQ_BF_SEG
-#define VAQ_BF_SEG 8
+#define VAQ_BF_SEG 64  // (with the prefetch working a unit's fixed cost is what counts: C2 8 / 16 / 32 / 64 / 128 steps 0.748 / 0.712 / 0.700 / 0.688 / 0.689 ms, C4 27.1 / - / 25.6 / 25.4 / 25.0)
 #endif
 #ifndef VAQ_BF_FLUSH
 #define VAQ_BF_FLUSH 16
