@@ -463,6 +463,8 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   BF_PRIO_SERIAL();
   const float *__restrict__ glut = p.lut + (size_t)qi * p.lut_floats;
   const int *__restrict__ bstart = p.bucket_start;
+  typedef const int __attribute__((address_space(4))) *const_int_ptr;
+  const const_int_ptr bstart_k = (const_int_ptr)(uintptr_t)p.bucket_start;
   const int nwaves = nthreads >> 6;
   const int bs_first = tid < K0 ? bstart[tid] : 0, be_first = tid < K0 ? bstart[tid + 1] : 0;
   for (int e = tid; e < lut_entries; e += nthreads) lut[e] = glut[e];
@@ -912,13 +914,46 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       i = wbase + cnt;
       key = (unsigned)__builtin_amdgcn_readfirstlane((int)keys[i]);
       const int b = (int)(key & idx_mask);
-      bs_raw = bstart[b];
-      be_raw = bstart[b + 1];
+      // (read through the constant address space: wave-uniform index, table not written by the
+      //  kernel -> scalar loads, which count on lgkmcnt; as vector loads they are younger than the
+      //  code items already in flight for this unit, and waiting for them would drain those)
+      bs_raw = bstart_k[b];
+      be_raw = bstart_k[b + 1];
     };
+    // rows [pos, be) of unit tt (the (tt - cum[ii])-th of its bucket), the aligned row of its first
+    // item and its wave steps
+    auto geometry = [&](const int tt, const int ii, const int bsr, const int ber, int &pos, int &be, int &base0,
+                        int &nst) {
+      const int bs = __builtin_amdgcn_readfirstlane(bsr > r0 ? bsr : r0);
+      const int bend = __builtin_amdgcn_readfirstlane(ber < r1 ? ber : r1);
+      const int j = tt - __builtin_amdgcn_readfirstlane(cum[ii]);
+      const int al = bs & ~(WSTEP - 1);
+      pos = al + j * SEG_ROWS;
+      if (pos < bs) pos = bs;
+      be = al + (j + 1) * SEG_ROWS;
+      if (be > bend) be = bend;
+      base0 = pos & ~(WSTEP - 1);
+      nst = (be - base0 + WSTEP - 1) / WSTEP;
+    };
+    // BF_RING code items in flight per wave, ACROSS units: while the last steps of a unit are
+    // worked through, the slots they free take the first items of the next one, so only a round's
+    // first unit waits for memory.  Every path issues the SAME number of loads (one past a unit's
+    // end re-reads its last item -- a cache hit; the last unit of a round re-reads its own): a
+    // load that is issued on some paths only leaves the compiler no count it can wait for but
+    // zero, and every step then waits for the load issued just before it -- no prefetch at all
+    // (seen in the ISA: s_waitcnt vmcnt(0) at each step; now it is vmcnt(BF_RING - 1)).
+    Item ring[BF_RING];
     int t = take_ticket();
-    int i = 0, bs_raw = 0, be_raw = 0;
+    int i = 0;
     unsigned key = 0u;
-    if (t < total_units) locate(t, i, key, bs_raw, be_raw);
+    int pos = 0, be = 0, base0 = 0, nst = 1;
+    if (t < total_units) {
+      int bs_raw, be_raw;
+      locate(t, i, key, bs_raw, be_raw);
+      geometry(t, i, bs_raw, be_raw, pos, be, base0, nst);
+#pragma unroll
+      for (int u = 0; u < BF_RING; u++) Pol::load(ring[u], codes, base0 + (u < nst - 1 ? u : nst - 1) * WSTEP, lane);
+    }
     while (t < total_units) {
       const int t_next = take_ticket();
       STAT_ADD(ST_BUCKETS_TESTED, 1);
@@ -928,21 +963,12 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       if (!p.no_skip && lbv > thr_d) break;
       STAT_ADD(ST_BUCKETS_VISITED, 1);
       const int b = (int)(key & idx_mask);
-      const int bs = __builtin_amdgcn_readfirstlane(bs_raw > r0 ? bs_raw : r0);
-      const int bend = __builtin_amdgcn_readfirstlane(be_raw < r1 ? be_raw : r1);
-      const int j = t - __builtin_amdgcn_readfirstlane(cum[i]);
-      const int al = bs & ~(WSTEP - 1);
-      int pos = al + j * SEG_ROWS;
-      if (pos < bs) pos = bs;
-      int be = al + (j + 1) * SEG_ROWS;
-      if (be > bend) be = bend;
       // the rows' shared first term (fine buckets)
       const float l0 = UL0 ? bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[b >> bt]))) : 0.0f;
-      const int base0 = pos & ~(WSTEP - 1);
-      const int nst = (be - base0 + WSTEP - 1) / WSTEP;
+      const bool has_next = t_next < total_units;
       int i_n = 0, bs_n = 0, be_n = 0;
       unsigned key_n = 0u;
-      if (t_next < total_units) locate(t_next, i_n, key_n, bs_n, be_n);
+      if (has_next) locate(t_next, i_n, key_n, bs_n, be_n);
 
       auto step = [&](const Item &cur, const int st) {
         const int base = base0 + st * WSTEP;
@@ -986,15 +1012,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
         }
       };
 
-      // BF_RING code items in flight per wave.  Every path through the loop issues the SAME number
-      // of loads (one past the unit's end re-reads its last item: a cache hit): a load that is
-      // issued on some paths only leaves the compiler no count it can wait for but zero, and every
-      // step then waits for the load issued just before it -- no prefetch at all (seen in the ISA:
-      // s_waitcnt vmcnt(0) at each step; with uniform counts it is vmcnt(BF_RING - 1)).
-      Item ring[BF_RING];
       const int last = nst - 1;  // (nst >= 1: a unit has rows)
-  #pragma unroll
-      for (int u = 0; u < BF_RING; u++) Pol::load(ring[u], codes, base0 + (u < last ? u : last) * WSTEP, lane);
       int st = 0;
       for (; st + BF_RING < nst; st += BF_RING) {
   #pragma unroll
@@ -1004,14 +1022,21 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
           Pol::load(ring[u], codes, base0 + (nx < last ? nx : last) * WSTEP, lane);
         }
       }
+      // the unit's last steps; each slot then takes its item of the next unit
+      int pos_n = pos, be_n2 = be, base0_n = base0 + last * WSTEP, nst_n = 1;  // (no next unit: this one's last item again)
+      if (has_next) geometry(t_next, i_n, bs_n, be_n, pos_n, be_n2, base0_n, nst_n);
   #pragma unroll
-      for (int u = 0; u < BF_RING; u++)
+      for (int u = 0; u < BF_RING; u++) {
         if (st + u < nst) step(ring[u], st + u);
+        Pol::load(ring[u], codes, base0_n + (u < nst_n - 1 ? u : nst_n - 1) * WSTEP, lane);
+      }
       t = t_next;
       i = i_n;
       key = key_n;
-      bs_raw = bs_n;
-      be_raw = be_n;
+      pos = pos_n;
+      be = be_n2;
+      base0 = base0_n;
+      nst = nst_n;
     }
     PH_MARK(4);
     // the round's buckets are done (or out of reach); empty the wave's buffers, which the next
