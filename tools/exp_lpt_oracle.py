@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Experiment: what would longest-first dispatch buy the C2 scan if a query's cost were known
+exactly?  A VAQ_WGTIME build (VAQ_VARIANT=wgtime VAQ_EXTRA_FLAGS=-DVAQ_WGTIME) returns every
+workgroup's lifetime in place of the k-th distance; the batch is then re-run with the queries in
+descending order of that time, and with only the top p % moved to the front."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VAQHIP_LIB"] = os.path.join(ROOT, "vaq_amd/lib/variants/wgtime/libvaqhip.so")
+import numpy as np, torch
+import bench
+from vaq_amd import harness
+
+dev = torch.device("cuda", 0)
+v, _, cents, _ = bench.build_index([8] * 8, 1_000_000, 0, 1_000_000, dev, 0, 1, 0, iters=15)
+v.set_option("group_queries", 0)
+q = harness.sift_like(10_000, 128, stream=7, device=dev)
+
+def scan_ms(qq, reps=10):
+    v.set_option("timing", 0)
+    for _ in range(3):
+        v.search_device(qq, 100)
+    torch.cuda.synchronize()
+    v.set_option("timing", 1); v.last_timing()
+    for _ in range(reps):
+        v.search_device(qq, 100)
+    torch.cuda.synchronize()
+    return v.last_timing()["scan_ms"]
+
+lab, dist = v.search_device(q, 100)
+torch.cuda.synchronize()
+cyc = dist.reshape(10000, 100)[:, 99].float().cpu().numpy()
+print("workgroup lifetime (counter units): mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" %
+      (cyc.mean(), np.median(cyc), np.quantile(cyc, 0.9), np.quantile(cyc, 0.99), cyc.max()))
+print("as given: %.4f ms" % scan_ms(q))
+order = np.argsort(-cyc)
+print("longest first (exact): %.4f ms" % scan_ms(q[torch.from_numpy(order.copy()).to(dev)].contiguous()))
+print("shortest first: %.4f ms" % scan_ms(q[torch.from_numpy(order[::-1].copy()).to(dev)].contiguous()))
+for pct in (1, 3, 10, 30):
+    n = 10000 * pct // 100
+    top = order[:n]
+    rest = np.setdiff1d(np.arange(10000), top, assume_unique=False)
+    o = np.concatenate([top, rest])
+    print("top %d %% first: %.4f ms" % (pct, scan_ms(q[torch.from_numpy(o).to(dev)].contiguous())))
+# interleaved: long and short alternate (every 8th workgroup is one of the longest)
+rng = np.random.default_rng(1)
+o = order.copy()
+blocks = o.reshape(8, 1250)  # rows: cost octiles, longest first
+print("octiles interleaved (one of each per 8 workgroups): %.4f ms" % scan_ms(q[torch.from_numpy(blocks.T.reshape(-1).copy()).to(dev)].contiguous()))

@@ -456,6 +456,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
   // ---- setup ----
+#ifdef VAQ_WGTIME
+  const unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
 #ifdef VAQ_PHASES
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long ph_t = __builtin_readcyclecounter();
@@ -981,8 +984,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   #pragma unroll
         for (int r = 0; r < ROWS; r++) {
           part[r] = pol.template first_two<UL0>(cur, r, l0);  // A: dism = l0; dism += l1
-          alive[r] = !(part[r] > thr_d);
-          if (!interior) alive[r] = alive[r] && (row0 + r >= pos) && (row0 + r < be);
+          // (interior is wave-uniform: the row-range test folds into scalar mask logic)
+          const bool in_range = interior || ((row0 + r >= pos) && (row0 + r < be));
+          alive[r] = in_range && !(part[r] > thr_d);
           STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
         }
   #pragma unroll
@@ -1124,6 +1128,10 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     if (p.stats && lane == 0) atomicAdd(&p.stats[ST_CYC_FINAL], __builtin_readcyclecounter() - t_fin);
 #endif
   }
+#ifdef VAQ_WGTIME  // (experiment builds: the workgroup's lifetime in place of the k-th distance, tools/exp_lpt_oracle.py)
+  if (wave == 0 && lane == 0 && p.final_dist)
+    p.final_dist[(size_t)qi * k + (k - 1)] = (float)(__builtin_readcyclecounter() - wg_t0);
+#endif
 #ifdef VAQ_PHASES
   PH_MARK(7);
   if (p.stats && lane == 0 && (blockIdx.x & 63) == 0) {  // (a sample: same-address atomics from every wave would be the slowest thing in the kernel)
