@@ -873,10 +873,11 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     // rank sort (n <= BF_ROUND_BUCKETS): position = number of smaller keys
     for (int i = tid; i < n; i += nthreads) {
       const unsigned key = kuns[i];
+      const int units = units_of(key);  // (two reads of bucket_start: in flight while the rank is counted)
       int rank = 0;
       for (int j = 0; j < n; j++) rank += kuns[j] < key ? 1 : 0;
       keys[rank] = key;
-      cum[rank + 1] = units_of(key);
+      cum[rank + 1] = units;
     }
     if (tid == 0) *ticket = 0u;
     __syncthreads();
@@ -1071,12 +1072,16 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   if (p.stats && lane == 0)
     for (int i = 0; i < ST_N; i++) atomicAdd(&p.stats[i], cx.st[i]);
 #endif
+  // wave 0 cuts the pool to exactly the k best (ties cut by label); the waves then share the ordering
   if (wave == 0) {
-    STAT_T0(t_fin);
-    int n = (int)sel.hdr[SEL_NCAND];
+    const int n0 = (int)sel.hdr[SEL_NCAND];
     PH_MARK(8);
-    if (n > k) n = pool_compact(sel, n, k, cap, cap, lane);  // exactly the k best (ties cut by label)
+    if (n0 > k) pool_compact(sel, n0, k, cap, cap, lane);  // (leaves the new count in the header)
     PH_MARK(9);
+  }
+  __syncthreads();
+  {
+    const int n = (int)sel.hdr[SEL_NCAND];
     // result slot i: the API's format when this list IS the result (one slice per query;
     // heap_reorder's: ascending, empty slots -1 / FLT_MAX, utils/Heap.hpp:322-349), else a
     // partial list for the merge
@@ -1095,8 +1100,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       // Few rows: each lane counts the rows below its own -- (distance bits, label) compared as
       // one 64-bit key, distinct because labels are -- and writes its row at that position.
       // The other rows are broadcast reads of LDS, independent of each other: no chain of
-      // dependent compare-exchange stages as in a sorting network (28 for 128 rows).
-      for (int base = 0; base < n; base += 64) {
+      // dependent compare-exchange stages as in a sorting network (28 for 128 rows).  Wave w takes
+      // rows [64 w, 64 w + 64), ...
+      for (int base = wave * 64; base < n; base += nwaves * 64) {
         const int i = base + lane;
         const bool valid = i < n;
         const float di = valid ? sel.d[i] : INFINITY;
@@ -1110,8 +1116,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
         }
         if (valid) emit(rank, di, ii);
       }
-      for (int i = n + lane; i < k; i += 64) emit(i, INFINITY, ID_SENTINEL);
-    } else {
+      if (wave == nwaves - 1)
+        for (int i = n + lane; i < k; i += 64) emit(i, INFINITY, ID_SENTINEL);
+    } else if (wave == 0) {
       int P = 2;
       while (P < n) P <<= 1;
       const int pad_to = P > kp ? P : kp;
@@ -1123,10 +1130,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       bitonic_sort<false>(sel.d, sel.id, P, lane, 64);  // ascending by (distance, label)
       for (int i = lane; i < k; i += 64) emit(i, sel.d[i], sel.id[i]);
     }
-    if (!p.final_labels && lane == 0) p.part_cnt[(size_t)qi * p.n_slices + slice] = n < k ? n : k;
-#ifdef VAQ_STATS
-    if (p.stats && lane == 0) atomicAdd(&p.stats[ST_CYC_FINAL], __builtin_readcyclecounter() - t_fin);
-#endif
+    if (!p.final_labels && tid == 0) p.part_cnt[(size_t)qi * p.n_slices + slice] = n < k ? n : k;
   }
 #ifdef VAQ_WGTIME  // (experiment builds: the workgroup's lifetime in place of the k-th distance, tools/exp_lpt_oracle.py)
   if (wave == 0 && lane == 0 && p.final_dist)

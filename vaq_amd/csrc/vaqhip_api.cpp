@@ -522,8 +522,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                                       ix->sub[1].ncent, ix->w_qorder.as<int>(), st));
       sp.qorder = ix->w_qorder.as<int>();
     }
-    // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff)
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
+    // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff); a query
+    // served by ONE workgroup and no pre-pass never reads the word (share_thr = 0 below)
+    if (pl.n_slices > 1 || pl.seed_slices > 0)
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
     if (ti) {
       // VAQ::search's TI branch (VAQ.cpp:799-826) then VAQ::searchTriangleInequality (:1540-1692)
       const int T = ix->ti_T;
