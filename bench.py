@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--seed-frac", type=int, default=0, help="pre-pass scans N / this many rows (0 = default 64)")
     ap.add_argument("--hot", type=int, default=-1, help="best-first buckets per workgroup (0..32, -1 = default)")
     ap.add_argument("--bf", type=int, default=-1, help="best-first scan form on/off (-1 = library default)")
+    ap.add_argument("--defer", type=int, default=-1, help="work units of a query's first round before the rest goes to a "
+                                                          "second launch (0 = off, -1 = library default)")
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
                                              "seg subspaces (default all), method EA_TI (not the headline metric)")
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
@@ -424,6 +426,8 @@ def main():
         v.set_option("bucket_skip", 0)
     if args.bf >= 0:
         v.set_option("best_first", args.bf)
+    if args.defer >= 0:
+        v.set_option("defer_units", args.defer)
     info = v.info()
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the

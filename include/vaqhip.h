@@ -312,6 +312,12 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       bound, work units handed to its waves by ticket, and stops at the first
  *                       bucket out of reach ("best-first form"); 0: the
  *                       16-hot-buckets-then-natural-order form.  Results are identical.
+ *   "defer_units"       0 (default) = off; n > 0: with one best-first workgroup per query, a
+ *                       query's first round takes at most n work units (64 wave steps each); the
+ *                       buckets still in reach after it are scanned by a second launch, two
+ *                       workgroups per query, and merged in (-1: n = 96 from 4096 queries per call
+ *                       on).  Results are identical.  Measured slower than scanning on in place
+ *                       (DESIGN.md section 4): the second launch has a tail of its own.
  *   "bucket_bits"       0 (default) = auto, else 1..12: width of the key the rows are bucketed by
  *                       (top bits of the first code, continued into the second); takes
  *                       effect when the codes are (re)set
@@ -333,6 +339,8 @@ typedef struct {
   int seed_slices;                             /* row slices of the pre-pass (0 = none) */
   int early_abandon;                           /* form the scan ran in: 0 none, 1 queue, 2 in place */
   int best_first;                              /* 1: the best-first form ("best_first" option) ran */
+  int deferred_queries;                        /* queries of the last search cut in two ("defer_units"): handed
+                                                  to the second launch; -1 = the search did not defer */
 } vaqhip_timing;
 int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
 

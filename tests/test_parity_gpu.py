@@ -709,3 +709,38 @@ def test_best_first_pool_tie_cut(vaqlib, oracle, k):
             assert ties >= 1 or k == 1
     assert ran >= 2, ran
     v.close()
+
+
+@pytest.mark.parametrize("bits,k", [([8] * 8, 100), ([8] * 16, 10), ([12, 10, 9, 8, 8, 7, 6, 4], 37), ([4] * 8, 100)],
+                         ids=["m8", "m16", "nonuniform", "ties"])
+def test_best_first_deferred_queries(vaqlib, oracle, bits, k):
+    """Expensive queries cut in two ("defer_units"): a first round of a few work units, the buckets
+    still in reach after it scanned by a second launch (two workgroups per query sharing a
+    threshold) and merged into the first launch's result.  Forced with 1, 2 and 8 units, where
+    nearly every query is handed over -- and more of them than the hand-over list holds, so some
+    scan on in place -- against the oracle and against the undivided scan (bit-identical)."""
+    N, nq = 200_000, 2500
+    c = make_case(7100 + k, 4 * len(bits), bits, N, nq, dup_frac=0.02, integer=(bits[0] == 4))
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True, nthreads=8)
+    v = make_index(c)
+    v.set_option("timing", 1)
+    v.set_option("defer_units", 0)
+    base = v.search(c["X"], k)
+    assert v.last_timing()["best_first"] == 1
+    ad = oracle_all_dists(oracle, c, Xp[:64])
+    assert_topk_matches(base.labels.reshape(nq, k)[:64], base.distances.reshape(nq, k)[:64], o_lab[:64], o_dis[:64], ad,
+                        what="undivided")
+    assert np.array_equal(base.distances.reshape(nq, k), o_dis)
+    handed = {}
+    for units in (1, 2, 8, -1):
+        v.set_option("defer_units", units)
+        for rep in range(2):
+            a = v.search(c["X"], k)
+            handed[units] = v.last_timing()["deferred_queries"]
+            assert np.array_equal(a.distances, base.distances), (units, rep)
+            assert np.array_equal(a.labels, base.labels), (units, rep)
+    assert handed[1] == 2048, handed           # more expensive queries than the list holds
+    assert handed[1] >= handed[2] >= handed[8] >= 1, handed
+    assert handed[-1] == -1, handed            # the automatic rule: fewer than 4096 queries, not deferring
+    v.close()

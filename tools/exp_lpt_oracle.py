@@ -14,6 +14,7 @@ from vaq_amd import harness
 dev = torch.device("cuda", 0)
 v, _, cents, _ = bench.build_index([8] * 8, 1_000_000, 0, 1_000_000, dev, 0, 1, 0, iters=15)
 v.set_option("group_queries", 0)
+v.set_option("defer_units", 0)
 q = harness.sift_like(10_000, 128, stream=7, device=dev)
 
 def scan_ms(qq, reps=10):
@@ -32,6 +33,13 @@ torch.cuda.synchronize()
 cyc = dist.reshape(10000, 100)[:, 99].float().cpu().numpy()
 print("workgroup lifetime (counter units): mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" %
       (cyc.mean(), np.median(cyc), np.quantile(cyc, 0.9), np.quantile(cyc, 0.99), cyc.max()))
+D = dist.reshape(10000, 100).float().cpu().numpy()
+names = ["steps", "drains", "flushes", "pool compactions", "eligible buckets", "rounds"]
+import scipy.stats as st
+for j, nm in enumerate(names):
+    x = D[:, 98 - j]
+    top = np.argsort(-cyc)[:100]
+    print("%-18s mean %.1f  top-1%% by lifetime mean %.1f  spearman with lifetime %.3f" % (nm, x.mean(), x[top].mean(), st.spearmanr(x, cyc).correlation))
 print("as given: %.4f ms" % scan_ms(q))
 order = np.argsort(-cyc)
 print("longest first (exact): %.4f ms" % scan_ms(q[torch.from_numpy(order.copy()).to(dev)].contiguous()))

@@ -37,6 +37,14 @@ constexpr int SCAN_MAX_WAVES = 16;
 // sentinel id of an empty candidate slot (sorts after every real id)
 constexpr int ID_SENTINEL = 0x7fffffff;
 
+// one query handed from the first launch of the best-first form to the second (ScanParams::defer_*)
+struct DeferRec {
+  int q;              // query (index within the call)
+  unsigned done_key;  // buckets with keys <= this were scanned by the first launch
+  unsigned thr;       // its threshold when it stopped (float bits): an upper bound of the final k-th distance
+  int pad;
+};
+
 struct ScanParams {
   const uint32_t *codes;  // packed codes (layout-specific)
   int64_t n_rows;         // local rows
@@ -85,6 +93,16 @@ struct ScanParams {
   int bf_carry;           // bit-packed best-first form: 1 = the groups after the first lie in the row's last
                           //    dword, which is carried through the survivor queue
   int bf_pool;            // best-first form: slots of the k-min pool (scan_bf_pool_range, multiple of 64)
+  // best-first form, ONE workgroup per query (n_slices == 1): the expensive queries are cut in two.
+  //   defer_units > 0   the first round takes at most this many work units (nearest buckets first);
+  //                     what is still in reach when it is over goes to defer_list instead of a
+  //                     second round, and a SECOND launch serves it with n_slices workgroups each
+  //   defer_mode == 1   this is that second launch: workgroup v serves entry v / n_slices of
+  //                     defer_list, rows of slice v % n_slices, starting from the entry's threshold
+  //                     and skipping the buckets at or below its done_key; lists go to part_d/part_id
+  int defer_units, defer_mode, defer_cap;
+  unsigned *defer_count;  // entries asked for so far (beyond defer_cap: not handed over, scanned in place)
+  struct DeferRec *defer_list;
   int bf;                 // 1: best-first form (vaq_scan_bf.h): all buckets of the slice in ascending order
                           //    of their bound, work units by ticket (needs qb == 1, ea == EA_QUEUE, no TI)
   int ti;                 // 1: TI form
@@ -164,6 +182,11 @@ void scan_bf_pool_range(int k, int *lo, int *hi);
 // (merge_scratch_elems() elements each).
 size_t merge_scratch_elems(int n_lists, int nq, int k);
 // part_cnt (optional, scan partials only): real entries per list, [nq][n_lists]
+// queries cut in two by the best-first form (ScanParams::defer_*): the first launch's result (already in
+// labels/dist, the API's format) and the n_lists lists of the second -> the k best, in place
+hipError_t launch_defer_merge(const unsigned *defer_count, int defer_cap, const DeferRec *defer_list, int n_lists, int k,
+                              const float *part_d, const int *part_id, const int *part_cnt, int64_t id_base,
+                              int32_t *labels, float *dist, hipStream_t st);
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,

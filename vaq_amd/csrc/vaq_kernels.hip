@@ -879,6 +879,74 @@ size_t merge_scratch_elems(int n_lists, int nq, int k) {
   return lists * (size_t)nq * k;
 }
 
+// ---------------------------------------------------------------------------
+// Queries the best-first form cut in two (ScanParams::defer_*).  The first launch wrote the k best
+// of the buckets it scanned to labels/dist (the API's format: ascending, -1 / FLT_MAX in empty
+// slots, labels with id_base added); the second launch's workgroups wrote n_lists partial lists
+// (local labels) of the other buckets -- disjoint rows, so every (distance, label) pair is distinct.
+// One workgroup per handed-over query: each thread counts the pairs below its own, compared as one
+// 64-bit key, and writes its pair at that position if it is among the k best (VAQ::searchHeap's
+// result is the k smallest pairs whatever the order they were met in, VAQ.cpp:1729-1758).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void defer_merge_kernel(const unsigned *__restrict__ defer_count, int defer_cap,
+                                                          const DeferRec *__restrict__ defer_list, int n_lists, int k,
+                                                          const float *__restrict__ part_d,
+                                                          const int *__restrict__ part_id,
+                                                          const int *__restrict__ part_cnt, int64_t id_base,
+                                                          int32_t *labels, float *dist) {
+  extern __shared__ unsigned long long dk[];  // [(1 + n_lists) * k] keys, ~0 = empty
+  __shared__ unsigned n_valid;
+  const unsigned asked = *defer_count;
+  const int cnt = asked < (unsigned)defer_cap ? (int)asked : defer_cap;
+  const int e = blockIdx.x;
+  if (e >= cnt) return;
+  const int q = defer_list[e].q;
+  const int total = (1 + n_lists) * k;
+  if (threadIdx.x == 0) n_valid = 0u;
+  __syncthreads();
+  unsigned mine = 0u;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int l = i / k, t = i - l * k;
+    unsigned long long key = ~0ull;
+    if (l == 0) {
+      const int32_t lab = labels[(size_t)q * k + t];
+      if (lab >= 0) key = ((unsigned long long)__float_as_uint(dist[(size_t)q * k + t]) << 32) | (unsigned)((int64_t)lab - id_base);
+    } else {
+      const size_t li = (size_t)e * n_lists + (l - 1);
+      if (t < part_cnt[li])
+        key = ((unsigned long long)__float_as_uint(part_d[li * k + t]) << 32) | (unsigned)part_id[li * k + t];
+    }
+    dk[i] = key;
+    mine += key != ~0ull ? 1u : 0u;
+  }
+  if (mine) atomicAdd(&n_valid, mine);
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const unsigned long long ki = dk[i];
+    if (ki == ~0ull) continue;
+    int rank = 0;
+    for (int j = 0; j < total; j++) rank += dk[j] < ki ? 1 : 0;
+    if (rank < k) {
+      labels[(size_t)q * k + rank] = (int32_t)((int64_t)(int)(unsigned)(ki & 0xffffffffull) + id_base);
+      dist[(size_t)q * k + rank] = __uint_as_float((unsigned)(ki >> 32));
+    }
+  }
+  for (int i = (int)n_valid + (int)threadIdx.x; i < k; i += blockDim.x) {
+    labels[(size_t)q * k + i] = -1;
+    dist[(size_t)q * k + i] = FLT_MAX;
+  }
+}
+
+hipError_t launch_defer_merge(const unsigned *defer_count, int defer_cap, const DeferRec *defer_list, int n_lists, int k,
+                              const float *part_d, const int *part_id, const int *part_cnt, int64_t id_base,
+                              int32_t *labels, float *dist, hipStream_t st) {
+  const size_t lds = (size_t)(1 + n_lists) * k * sizeof(unsigned long long);
+  if (lds > 60 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(defer_merge_kernel, dim3(defer_cap), dim3(256), lds, st, defer_count, defer_cap, defer_list, n_lists,
+                     k, part_d, part_id, part_cnt, id_base, labels, dist);
+  return hipGetLastError();
+}
+
 hipError_t launch_merge(const float *part_d, const int *part_id, const int *part_cnt, int n_lists,
                         int64_t list_stride, int64_t query_stride, int nq, int k, int64_t id_base,
                         int in_final, int32_t *labels, float *dist, unsigned *thr_out,

@@ -408,8 +408,25 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const int total = p.nq * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
   if (v >= total) return;
-  const int slice = v / p.nq;
-  const int qi = v - slice * p.nq;
+  // (second launch of a deferring scan, ScanParams::defer_mode: the query comes from defer_list)
+  const bool defer2 = p.defer_mode != 0;
+  int slice, qi, ent = 0;
+  unsigned rec_done = 0u, rec_thr = 0u;
+  if (defer2) {
+    const unsigned asked = *p.defer_count;
+    const int cnt = asked < (unsigned)p.defer_cap ? (int)asked : p.defer_cap;
+    ent = v / p.n_slices;
+    slice = v - ent * p.n_slices;
+    if (ent >= cnt) return;
+    const DeferRec rec = p.defer_list[ent];
+    qi = __builtin_amdgcn_readfirstlane(rec.q);
+    rec_done = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.done_key);
+    rec_thr = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.thr);
+  } else {
+    slice = v / p.nq;
+    qi = v - slice * p.nq;
+  }
+  const int out_q = defer2 ? ent : qi;  // where this workgroup's list goes among the partial lists
   const int r0 = (int)((int64_t)slice * p.slice_stride);
   const int64_t r1l = (int64_t)r0 + p.slice_rows;
   const int r1 = (int)(r1l > p.n_rows ? p.n_rows : r1l);
@@ -458,6 +475,10 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // ---- setup ----
 #ifdef VAQ_WGTIME
   const unsigned long long wg_t0 = __builtin_readcyclecounter();
+  int wg_drains = 0, wg_flushes = 0, wg_compacts = 0, wg_elig = 0, wg_rounds = 0;
+#define WG_COUNT(x) (x)++
+#else
+#define WG_COUNT(x)
 #endif
 #ifdef VAQ_PHASES
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -480,6 +501,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       const unsigned g = __hip_atomic_load(&p.g_thr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (g < td) { td = g; ti = INT_MAX; }
     }
+    if (defer2 && rec_thr < td) { td = rec_thr; ti = INT_MAX; }  // (rows AT the first launch's threshold stay admissible)
     sel.hdr[SEL_LOCK] = 0u;
     sel.hdr[SEL_NCAND] = 0u;
     sel.hdr[SEL_NBEST] = 0u;
@@ -612,6 +634,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     const int srow = cb_row[slot];
     const bool cand = has && !(d > thr_d);  // the threshold may have moved since the row was gathered
     if (__ballot(cand) == 0ull) return;
+    WG_COUNT(wg_flushes);
     STAT_T0(t_fl);
     STAT_ADD(ST_ADMITS, 1);
     const int rid = (cand && perm) ? (int)perm[srow] : srow;  // labels are ORIGINAL rows: ties break by them
@@ -632,6 +655,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       if (cnt + __popcll(m) > cap) {
         STAT_T0(t_fo);
         STAT_ADD(ST_FOLDS, 1);
+        WG_COUNT(wg_compacts);
         cnt = pool_compact(sel, cnt, k, cap, 64, lane);
         td = bits_to_float(sel.hdr[SEL_THR_D]);
         ti = (int)sel.hdr[SEL_THR_ID];
@@ -703,6 +727,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // phase B: the top n (<= 64) queue entries, one per lane: groups 1.. of the row, abandoning
   // after each (VAQ.cpp:1708)
   auto drain = [&](const int n) {
+    WG_COUNT(wg_drains);
     STAT_T0(t_dr);
     STAT_ADD(ST_DRAINS, 1);
     qcnt -= n;
@@ -734,7 +759,14 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // admissible).  It also bounds which buckets can matter at all (below).
   const unsigned kmin = *sh_min;
   STAT_T0(t_boot);
-  if (BF_BOOT_STEPS > 0 && !p.no_skip && (kmin & empty_key) != empty_key) {
+  if (defer2) {
+    // the first launch's threshold is the bootstrap: histogram over [0, H] as below
+    if (tid == 0) {
+      const float H = bits_to_float(sel.hdr[SEL_THR_D]);
+      if (H > 0.0f && H < FLT_MAX) sel.hdr[BF_HDR_SCALE] = float_to_bits((float)BF_HIST_BINS / H);
+    }
+    __syncthreads();
+  } else if (BF_BOOT_STEPS > 0 && !p.no_skip && (kmin & empty_key) != empty_key) {
     const int bb = (int)(kmin & idx_mask);
     const int bs = bstart[bb] > r0 ? bstart[bb] : r0;
     const int bend = bstart[bb + 1] < r1 ? bstart[bb + 1] : r1;
@@ -795,8 +827,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // ---- rounds: the eligible buckets (bound not above the threshold, not done yet), nearest first,
   //      at most BF_ROUND_BUCKETS per round; thresholds fall while a round runs, so a second round
   //      is rarely anything but the check that nothing is left ----
-  bool first_round = true;
-  unsigned done_key = 0u;  // buckets with keys <= done_key are finished (after the first round)
+  bool first_round = !defer2;
+  bool defer_tried = false;
+  unsigned done_key = rec_done;  // buckets with keys <= done_key are finished (after the first round)
   for (;;) {
     BF_PRIO_SERIAL();
     PH_MARK(5);
@@ -826,7 +859,35 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     __syncthreads();
     int n = (int)*sh_cnt;
     if (n == 0) break;
+    if (p.defer_units > 0 && !first_round && !defer_tried) {
+      // A first round that was cut short (below) and buckets still in reach after it: an expensive
+      // query.  Hand the rest to the second launch, where several workgroups share it, instead of
+      // keeping the launch waiting for this one (a full list: scan on here).
+      defer_tried = true;
+      if (tid == 0) {
+        const unsigned idx = atomicAdd(p.defer_count, 1u);
+        const bool ok = idx < (unsigned)p.defer_cap;
+        if (ok) {
+          DeferRec rec;
+          rec.q = qi;
+          rec.done_key = done_key;
+          rec.thr = sel.hdr[SEL_THR_D];
+          rec.pad = 0;
+          p.defer_list[idx] = rec;
+          p.g_thr[qi] = rec.thr;  // the word the second launch's workgroups of this query share
+        }
+        sh_rot[0] = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool handed = sh_rot[0] != 0u;
+      __syncthreads();
+      if (handed) break;
+    }
     STAT_ADD(ST_FOLDS, n);
+#ifdef VAQ_WGTIME
+    wg_elig += n;
+    wg_rounds++;
+#endif
     if (n > BF_ROUND_BUCKETS) {
       // more eligible buckets than a round holds (weak or no bootstrap threshold): bisect for the
       // largest key bound that lets at most BF_ROUND_BUCKETS of them in
@@ -900,6 +961,18 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     STAT_T1(ST_CYC_PREP, t_prep);
     PH_MARK(3);
     BF_PRIO_SCAN();
+    if (p.defer_units > 0 && first_round && cum[n] > p.defer_units) {
+      // keep the nearest buckets whose units fit (at least one); the others wait for the next round,
+      // or for the second launch
+      int lo = 1, hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (cum[mid] <= p.defer_units) lo = mid;
+        else hi = mid - 1;
+      }
+      n = lo;
+      hi_key = keys[n - 1];
+    }
     const int total_units = cum[n];
     // window of the unit prefix in registers: lane j holds cum[wbase + j + 1]
     int wbase = 0;
@@ -1085,7 +1158,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     // result slot i: the API's format when this list IS the result (one slice per query;
     // heap_reorder's: ascending, empty slots -1 / FLT_MAX, utils/Heap.hpp:322-349), else a
     // partial list for the merge
-    const size_t o = p.final_labels ? (size_t)qi * k : ((size_t)qi * p.n_slices + slice) * k;
+    const size_t o = p.final_labels ? (size_t)qi * k : ((size_t)out_q * p.n_slices + slice) * k;
     auto emit = [&](const int i, const float d, const int id) {
       if (p.final_labels) {
         const bool ok = id != ID_SENTINEL;
@@ -1130,11 +1203,29 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       bitonic_sort<false>(sel.d, sel.id, P, lane, 64);  // ascending by (distance, label)
       for (int i = lane; i < k; i += 64) emit(i, sel.d[i], sel.id[i]);
     }
-    if (!p.final_labels && tid == 0) p.part_cnt[(size_t)qi * p.n_slices + slice] = n < k ? n : k;
+    if (!p.final_labels && tid == 0) p.part_cnt[(size_t)out_q * p.n_slices + slice] = n < k ? n : k;
   }
-#ifdef VAQ_WGTIME  // (experiment builds: the workgroup's lifetime in place of the k-th distance, tools/exp_lpt_oracle.py)
-  if (wave == 0 && lane == 0 && p.final_dist)
-    p.final_dist[(size_t)qi * k + (k - 1)] = (float)(__builtin_readcyclecounter() - wg_t0);
+#ifdef VAQ_WGTIME  // (experiment builds: the workgroup's lifetime and event counts in place of the last distances, tools/exp_lpt_oracle.py)
+  __syncthreads();
+  if (tid < 8) hist[tid] = 0u;
+  __syncthreads();
+  if (lane == 0) {
+    atomicAdd(&hist[0], (unsigned)stepno);
+    atomicAdd(&hist[1], (unsigned)wg_drains);
+    atomicAdd(&hist[2], (unsigned)wg_flushes);
+    atomicAdd(&hist[3], (unsigned)wg_compacts);
+  }
+  __syncthreads();
+  if (wave == 0 && lane == 0 && p.final_dist) {
+    float *o = p.final_dist + (size_t)qi * k;
+    o[k - 1] = (float)(__builtin_readcyclecounter() - wg_t0);
+    o[k - 2] = (float)hist[0];
+    o[k - 3] = (float)hist[1];
+    o[k - 4] = (float)hist[2];
+    o[k - 5] = (float)hist[3];
+    o[k - 6] = (float)wg_elig;
+    o[k - 7] = (float)wg_rounds;
+  }
 #endif
 #ifdef VAQ_PHASES
   PH_MARK(7);

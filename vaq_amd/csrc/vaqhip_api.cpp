@@ -63,6 +63,16 @@ constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
 constexpr size_t LDS_GRANULE = 1280;           // allocation unit assumed when counting resident workgroups
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
+// Best-first form, one workgroup per query, option "defer_units" (OFF by default): a first round
+// takes at most that many work units and what is still in reach after it is scanned by DEFER_SLICES
+// workgroups per query in a second launch (at most DEFER_CAP queries; the others scan on in place).
+// A query's cost spans 6x (C2: 318 wave steps on average, 1857 for the top 1 %) and a launch ends
+// with its most expensive workgroups -- but the second launch has a tail of its own (a workgroup's
+// setup, first round and final cut: ~0.1 ms with the chip nearly empty) and every handed-over query
+// pays the per-workgroup costs twice more: C2 0.715 ms without, 0.74-0.77 with 48-128 units, 0.88
+// with 24 (tools/exp_lpt_oracle.py has the cost statistics).  Kept as an option; -1 = the automatic
+// rule below, which no default selects.
+constexpr int DEFER_MIN_QUERIES = 4096, DEFER_UNITS = 96, DEFER_SLICES = 2, DEFER_CAP = 2048;
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
 constexpr int64_t BUCKET_MIN_ROWS_10 = 1900;   // ... before it takes a tenth key bit
 constexpr int64_t UPLOAD_CHUNK_ROWS = 1 << 22; // rows per host->device staging chunk
@@ -93,6 +103,7 @@ struct vaqhip_index {
   DevBuf d_ti_clusters, d_ti_clusters_t, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order, w_qorder;
+  DevBuf w_defer;  // [0] entries asked for, then DEFER_CAP records (best-first form, queries cut in two)
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
   // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
@@ -102,7 +113,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -138,6 +149,7 @@ struct Plan {
   bool bf = false;  // best-first scan form (vaq_scan_bf.h)
   int bf_carry = 0;
   int bf_pool = 0;
+  int defer_units = 0;  // > 0: expensive queries are cut in two (ScanParams::defer_*)
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -302,6 +314,8 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       pl->bf = true;
       pl->bf_carry = carry;
       pl->bf_pool = bpool;
+      if (s == 1 && k <= 256 && (ix->opt_defer > 0 || (ix->opt_defer < 0 && nq >= DEFER_MIN_QUERIES)))
+        pl->defer_units = ix->opt_defer > 0 ? ix->opt_defer : DEFER_UNITS;
       pl->nwaves = bnw;
       pl->lds = blds;
     }
@@ -410,6 +424,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     else ev = ix->ev.data() + (size_t)ix->ev_used * 6;
   }
   vaqhip_timing tm = {};
+  tm.deferred_queries = -1;
   Plan pl;
   const bool ti = ix->ti_T > 0;
   {
@@ -426,6 +441,12 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
   HIP_TRY(ix->w_part_cnt.ensure((size_t)chunk * nslots * sizeof(int)));
   HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
+  if (pl.defer_units > 0) {
+    HIP_TRY(ix->w_defer.ensure(16 + (size_t)DEFER_CAP * sizeof(vaq::DeferRec)));
+    HIP_TRY(ix->w_part_d.ensure((size_t)DEFER_CAP * DEFER_SLICES * k * sizeof(float)));
+    HIP_TRY(ix->w_part_id.ensure((size_t)DEFER_CAP * DEFER_SLICES * k * sizeof(int)));
+    HIP_TRY(ix->w_part_cnt.ensure((size_t)DEFER_CAP * DEFER_SLICES * sizeof(int)));
+  }
   {
     const size_t ms = vaq::merge_scratch_elems(nslots, chunk, k);
     HIP_TRY(ix->w_ms_d.ensure(std::max<size_t>(ms, 1) * sizeof(float)));
@@ -472,6 +493,11 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bf = 0;
     sp.bf_carry = 0;
     sp.bf_pool = 0;
+    sp.defer_units = 0;
+    sp.defer_mode = 0;
+    sp.defer_cap = 0;
+    sp.defer_count = nullptr;
+    sp.defer_list = nullptr;
     sp.no_skip = ix->opt_no_skip;
     sp.stats = nullptr;
 #if defined(VAQ_STATS) || defined(VAQ_PHASES)
@@ -609,7 +635,36 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bf = pl.bf ? 1 : 0;
     sp.bf_carry = pl.bf_carry;
     sp.bf_pool = pl.bf_pool;
+    const bool defer = pl.bf && pl.defer_units > 0 && direct;
+    if (defer) {
+      sp.defer_units = pl.defer_units;
+      sp.defer_cap = DEFER_CAP;
+      sp.defer_count = ix->w_defer.as<unsigned>();
+      sp.defer_list = reinterpret_cast<vaq::DeferRec *>(ix->w_defer.as<unsigned char>() + 16);
+      HIP_TRY(hipMemsetAsync(sp.defer_count, 0, sizeof(unsigned), st));
+    }
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+    if (defer) {
+      // second launch: what the expensive queries have left, DEFER_SLICES workgroups each (those
+      // beyond the list's length return at once), then their lists are merged into the results
+      vaq::ScanParams s2 = sp;
+      s2.defer_units = 0;
+      s2.defer_mode = 1;
+      s2.nq = DEFER_CAP;
+      s2.n_slices = DEFER_SLICES;
+      const int step2 = vaq::scan_wg_step_rows(ix->layout, ix->M);
+      int64_t rows2 = (ix->N + DEFER_SLICES - 1) / DEFER_SLICES;
+      rows2 = std::max<int64_t>(step2, ((rows2 + step2 - 1) / step2) * step2);
+      s2.slice_rows = rows2;
+      s2.slice_stride = rows2;
+      s2.share_thr = 1;
+      s2.final_labels = nullptr;
+      s2.final_dist = nullptr;
+      int grid2 = 0;
+      HIP_TRY(vaq::launch_scan(s2, &grid2, st));
+      HIP_TRY(vaq::launch_defer_merge(sp.defer_count, DEFER_CAP, sp.defer_list, DEFER_SLICES, k, sp.part_d, sp.part_id,
+                                      sp.part_cnt, ix->id_base, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st));
+    }
 #ifdef VAQ_PHASES
     if (pl.bf) {
       unsigned long long h[11];
@@ -650,6 +705,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     tm.seed_slices = pl.seed_slices;
     tm.early_abandon = pl.ea;
     tm.best_first = pl.bf ? 1 : 0;
+    tm.deferred_queries = defer ? 0 : -1;
     tm.queries_per_pass = pl.qb;
     tm.slices = pl.n_slices;
     tm.workgroups = grid;
@@ -1399,6 +1455,9 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     ix->opt_group = (int)value;
   } else if (k == "best_first") {
     ix->opt_bf = value != 0;
+  } else if (k == "defer_units") {
+    if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
+    ix->opt_defer = (int)value;
   } else if (k == "seed_thresholds") {
     ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
@@ -1434,6 +1493,11 @@ int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out) {
     ix->last.merge_ms = (float)(acc[4] / n);
     ix->last.n_searches = ix->ev_used;
     ix->ev_used = 0;
+    if (ix->last.deferred_queries >= 0 && ix->w_defer.p) {  // (the events above are past: the counter is final)
+      unsigned asked = 0;
+      HIP_TRY(hipMemcpy(&asked, ix->w_defer.p, sizeof asked, hipMemcpyDeviceToHost));
+      ix->last.deferred_queries = (int)std::min<unsigned>(asked, (unsigned)DEFER_CAP);
+    }
   }
   *out = ix->last;
   return VAQHIP_OK;
