@@ -55,3 +55,17 @@ rng = np.random.default_rng(1)
 o = order.copy()
 blocks = o.reshape(8, 1250)  # rows: cost octiles, longest first
 print("octiles interleaved (one of each per 8 workgroups): %.4f ms" % scan_ms(q[torch.from_numpy(blocks.T.reshape(-1).copy()).to(dev)].contiguous()))
+
+# keep the mix, but let no expensive query START late: expensive ones in the last part of the order
+# trade places with cheap ones from the first part
+for tail_frac, hard_q in ((0.3, 0.85), (0.3, 0.7), (0.5, 0.8), (0.2, 0.9)):
+    o = np.arange(10000)
+    cut = int(10000 * (1 - tail_frac))
+    thr_hard = np.quantile(cyc, hard_q)
+    late_hard = [i for i in range(cut, 10000) if cyc[i] > thr_hard]
+    early_easy = [i for i in range(0, cut) if cyc[i] < np.median(cyc)]
+    rng.shuffle(early_easy)
+    for a, b in zip(late_hard, early_easy):
+        o[a], o[b] = o[b], o[a]
+    print("expensive (> p%d) out of the last %d %%: %d swaps, %.4f ms" %
+          (int(hard_q * 100), int(tail_frac * 100), min(len(late_hard), len(early_easy)), scan_ms(q[torch.from_numpy(o).to(dev)].contiguous())))
