@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VAQHIP_VERSION 101
+#define VAQHIP_VERSION 102
 
 /* error codes */
 #define VAQHIP_OK            0
