@@ -235,8 +235,31 @@ __device__ __forceinline__ int pool_compact(const SelView &sel, const int n, con
 //   full            the complete row sum (bootstrap sample)
 // Arithmetic order is the reference's throughout (VAQ.cpp:1737-1748).
 // ---------------------------------------------------------------------------
+// (experiment knob: bytes of code one lane loads per wave step for 8-byte rows; 16 = 2 rows.  32 = 4 rows
+//  per lane and step with a ring of 3 measured slower at C2, 0.755 vs 0.725 ms, and level at C4)
+#ifndef VAQ_BF_M8_ITEM_BYTES
+#define VAQ_BF_M8_ITEM_BYTES 16
+#endif
+template <int M, int BYTES_> struct BfBytesItem {
+  static constexpr int BYTES = BYTES_;
+  static constexpr int ROWS = BYTES / M;
+  static constexpr int LOADS = BYTES / 16;
+  static constexpr int WPR = M / 4;  // dwords per row
+  uint4 w[LOADS];
+  __device__ __forceinline__ void load(const uint32_t *codes, int64_t item) {
+    const uint4 *c = reinterpret_cast<const uint4 *>(codes) + item * LOADS;
+#pragma unroll
+    for (int i = 0; i < LOADS; i++) w[i] = c[i];
+  }
+  __device__ __forceinline__ uint32_t word(int row, int g) const {
+    const int idx = row * WPR + g;
+    const uint4 x = w[idx / 4];
+    const int c = idx % 4;
+    return c == 0 ? x.x : c == 1 ? x.y : c == 2 ? x.z : x.w;
+  }
+};
 template <int M> struct BfBytes {
-  typedef BytesItem<M> Item;
+  typedef BfBytesItem<M, (M == 8 ? VAQ_BF_M8_ITEM_BYTES : (M < 16 ? 16 : M))> Item;
   static constexpr int ROWS = Item::ROWS;
   static constexpr int WPR = Item::WPR;
   static constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
