@@ -69,3 +69,24 @@ for tail_frac, hard_q in ((0.3, 0.85), (0.3, 0.7), (0.5, 0.8), (0.2, 0.9)):
         o[a], o[b] = o[b], o[a]
     print("expensive (> p%d) out of the last %d %%: %d swaps, %.4f ms" %
           (int(hard_q * 100), int(tail_frac * 100), min(len(late_hard), len(early_easy)), scan_ms(q[torch.from_numpy(o).to(dev)].contiguous())))
+
+# The kernel deals virtual ids to XCDs in contiguous ranges (xcd_virtual_id: XCD x serves queries
+# [x G/8, (x+1) G/8) in that order), so a sorted order gives ONE XCD all the expensive queries.
+# Longest-first done properly: rank r goes to XCD r % 8, position r // 8.
+def xcd_place(order):
+    G8 = len(order) // 8
+    out = np.empty_like(order)
+    r = np.arange(len(order))
+    out[(r % 8) * G8 + r // 8] = order
+    return out
+print("longest first, dealt over the XCDs: %.4f ms" % scan_ms(q[torch.from_numpy(xcd_place(order)).to(dev)].contiguous()))
+print("shortest first, dealt over the XCDs: %.4f ms" % scan_ms(q[torch.from_numpy(xcd_place(order[::-1].copy())).to(dev)].contiguous()))
+for pct in (1, 3, 10, 30):
+    n = 10000 * pct // 100
+    top = order[:n]
+    rest = np.setdiff1d(np.arange(10000), top)
+    rng.shuffle(rest)
+    o = np.concatenate([top, rest])
+    print("top %d %% first, dealt over the XCDs, rest shuffled: %.4f ms" % (pct, scan_ms(q[torch.from_numpy(xcd_place(o)).to(dev)].contiguous())))
+o = np.arange(10000); rng.shuffle(o)
+print("random shuffle: %.4f ms" % scan_ms(q[torch.from_numpy(o).to(dev)].contiguous()))

@@ -158,6 +158,10 @@ hipError_t launch_slice_order(const float *lut, int lut_floats, int nq, int qb, 
                               int n_buckets, int bucket_shift, int64_t slice_rows, int n_slices,
                               int64_t n_rows, int *order, hipStream_t st);
 // order[i] = the query the i-th pass slot takes: by (nearest first code, nearest second code); nq <= 16384
+// best-first form, one workgroup per query: order[b] = the query block b serves, expensive queries
+// first (keys: nq 64-bit scratch words; n0 = entries of table 0, shift = bucket_shift)
+hipError_t launch_cost_order(const float *lut, int lut_floats, int nq, int n0, int shift, unsigned long long *keys,
+                             int *order, hipStream_t st);
 hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, int off1, int n1, int *order,
                               hipStream_t st);
 // LDS geometry of a scan workgroup for top-k = k

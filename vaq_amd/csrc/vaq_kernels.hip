@@ -621,6 +621,117 @@ hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Dispatch order of the best-first form with one workgroup per query: expensive queries first.
+// A query's cost spans 6x (C2: 318 wave steps on average, 1857 for the top 1 %) and a launch ends
+// with its most expensive workgroups; started first they end inside the bulk (C2 scan 0.75 -> 0.55 ms
+// with this predictor, 0.50 with the exact costs: tools/exp_cost_predictor.py).  What makes a
+// query expensive is the number of buckets in its reach, i.e. how FLAT its first lookup table is
+// near the minimum: cost key = (16th smallest - smallest) of the per-bucket minima of table 0,
+// ascending (Spearman 0.65 with a workgroup's lifetime, 0.79 with its steps).
+//   query_cost_kernel   one wave per query -> key bits << 32 | query
+//   cost_sort_kernel    one workgroup: counting sort by the key's top bits -> order[b] = query of block b
+// Block b serves order[b]: blocks are dealt round-robin over the XCDs and dispatched in order, so
+// every XCD gets every 8th query of the ranking.  Speed only: any order is correct.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void query_cost_kernel(const float *__restrict__ lut, int lut_floats, int nq, int n0,
+                                                         int shift, unsigned long long *__restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const float *l = lut + (size_t)q * lut_floats;
+  const int nb = n0 >> shift;  // buckets at the level of the first code (<= 1024: 16 per lane)
+  unsigned v[16];
+  unsigned vmin = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int b = i * 64 + lane;
+    unsigned m = 0xffffffffu;  // (absent or NaN: never counted)
+    if (b < nb) {
+      for (int c = b << shift; c < ((b + 1) << shift); c++) {
+        const float x = l[c];
+        const unsigned xb = x == x ? float_to_bits(x) : 0xffffffffu;  // entries are >= 0: bit order == value order
+        m = xb < m ? xb : m;
+      }
+    }
+    v[i] = m;
+    vmin = m < vmin ? m : vmin;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned x = (unsigned)__shfl_xor((int)vmin, o);
+    vmin = x < vmin ? x : vmin;
+  }
+  const int J = nb < 16 ? nb : 16;
+  unsigned lo = vmin, hi = 0x7f800000u;  // smallest t with count(v <= t) >= J
+  if (vmin > hi) lo = hi;
+  while (lo < hi) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c += __popcll(__ballot(v[i] <= mid));
+    if (c >= J) hi = mid;
+    else lo = mid + 1u;
+  }
+  const float spread = bits_to_float(lo) - bits_to_float(vmin < 0x7f800000u ? vmin : 0x7f800000u);
+  const unsigned kb = spread == spread ? float_to_bits(spread) : 0x7f800000u;  // (>= 0; inf - inf: last)
+  if (lane == 0) keys[q] = ((unsigned long long)kb << 32) | (unsigned)q;
+}
+
+// One workgroup: counting sort of the queries by the top 12 value bits of their cost key (sign 0,
+// exponent, 4 mantissa bits: 6 % steps -- the ranking only has to put expensive queries ahead of cheap
+// ones; a full bitonic sort of 16 k keys in one workgroup takes longer than the launch it speeds up).
+constexpr int COST_CLASSES = 4096;
+__global__ __launch_bounds__(QORDER_THREADS) void cost_sort_kernel(const unsigned long long *__restrict__ keys, int nq,
+                                                                   int *__restrict__ order) {
+  __shared__ unsigned hist[COST_CLASSES];
+  __shared__ unsigned wave_tot[QORDER_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < COST_CLASSES; i += QORDER_THREADS) hist[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < nq; i += QORDER_THREADS) atomicAdd(&hist[(unsigned)(keys[i] >> 51) & (COST_CLASSES - 1)], 1u);
+  __syncthreads();
+  // exclusive prefix over the classes: 4 per thread, then a wave scan, then the waves' totals
+  constexpr int PER = COST_CLASSES / QORDER_THREADS;
+  unsigned c[PER], sum = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    c[j] = hist[tid * PER + j];
+    sum += c[j];
+  }
+  unsigned inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned x = (unsigned)__shfl_up((int)inc, o);
+    if (lane >= o) inc += x;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  unsigned base = inc - sum;
+  for (int w = 0; w < wave; w++) base += wave_tot[w];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    hist[tid * PER + j] = base;
+    base += c[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < nq; i += QORDER_THREADS) {
+    const unsigned long long kq = keys[i];
+    const unsigned pos = atomicAdd(&hist[(unsigned)(kq >> 51) & (COST_CLASSES - 1)], 1u);
+    order[pos] = (int)(kq & 0xffffffffu);
+  }
+}
+
+hipError_t launch_cost_order(const float *lut, int lut_floats, int nq, int n0, int shift, unsigned long long *keys,
+                             int *order, hipStream_t st) {
+  if (nq <= 0 || nq > QORDER_MAX || (n0 >> shift) > 1024 || (n0 >> shift) < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(query_cost_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, lut, lut_floats, nq, n0, shift, keys);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cost_sort_kernel, dim3(1), dim3(QORDER_THREADS), 0, st, keys, nq, order);
+  return hipGetLastError();
+}
+
 // __global__ entry points: the SGPR-capped one for EA_NONE / EA_QUEUE, a plain one for EA_INPLACE
 static int rows_per_item(int layout, int M) { return (layout == LAYOUT_BYTES && M < 16) ? 16 / M : 1; }
 

@@ -430,7 +430,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int total = p.nq * p.n_slices;
   const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
-  if (v >= total) return;
+  if (!p.qorder && v >= total) return;
   // (second launch of a deferring scan, ScanParams::defer_mode: the query comes from defer_list)
   const bool defer2 = p.defer_mode != 0;
   int slice, qi, ent = 0;
@@ -445,6 +445,12 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     qi = __builtin_amdgcn_readfirstlane(rec.q);
     rec_done = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.done_key);
     rec_thr = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.thr);
+  } else if (p.qorder) {
+    // one workgroup per query, expensive queries first (launch_cost_order): block b, dispatched b-th
+    // and dealt to XCD b % 8, serves the b-th query of the ranking
+    if ((int)blockIdx.x >= p.nq) return;
+    slice = 0;
+    qi = __builtin_amdgcn_readfirstlane(p.qorder[blockIdx.x]);
   } else {
     slice = v / p.nq;
     qi = v - slice * p.nq;

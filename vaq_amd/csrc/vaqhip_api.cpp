@@ -72,6 +72,8 @@ constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than t
 // pays the per-workgroup costs twice more: C2 0.715 ms without, 0.74-0.77 with 48-128 units, 0.88
 // with 24 (tools/exp_lpt_oracle.py has the cost statistics).  Kept as an option; -1 = the automatic
 // rule below, which no default selects.
+// (launch_cost_order pays from about one residency of workgroups on: 7 per CU)
+constexpr int COST_ORDER_MIN_QUERIES = 2048;
 constexpr int DEFER_MIN_QUERIES = 4096, DEFER_UNITS = 96, DEFER_SLICES = 2, DEFER_CAP = 2048;
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
 constexpr int64_t BUCKET_MIN_ROWS_10 = 1900;   // ... before it takes a tenth key bit
@@ -103,6 +105,7 @@ struct vaqhip_index {
   DevBuf d_ti_clusters, d_ti_clusters_t, d_ti_xcc, w_ti_order, w_ti_qcc, w_ti_nvisit;
   // workspace (grow-only, reused across searches)
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order, w_qorder;
+  DevBuf w_cost;   // [nq] cost keys of launch_cost_order
   DevBuf w_defer;  // [0] entries asked for, then DEFER_CAP records (best-first form, queries cut in two)
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
@@ -113,7 +116,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -150,6 +153,7 @@ struct Plan {
   int bf_carry = 0;
   int bf_pool = 0;
   int defer_units = 0;  // > 0: expensive queries are cut in two (ScanParams::defer_*)
+  bool cost_order = false;  // one best-first workgroup per query: expensive queries are dispatched first
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -316,6 +320,9 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       pl->bf_pool = bpool;
       if (s == 1 && k <= 256 && (ix->opt_defer > 0 || (ix->opt_defer < 0 && nq >= DEFER_MIN_QUERIES)))
         pl->defer_units = ix->opt_defer > 0 ? ix->opt_defer : DEFER_UNITS;
+      // more queries than workgroups resident at a time: start the expensive ones first
+      pl->cost_order = s == 1 && ix->opt_cost_order && nq >= COST_ORDER_MIN_QUERIES && nq <= QUERY_CHUNK &&
+                       (ix->sub[0].ncent >> ix->bucket_shift) <= 1024;
       pl->nwaves = bnw;
       pl->lds = blds;
     }
@@ -441,6 +448,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   HIP_TRY(ix->w_part_id.ensure((size_t)chunk * nslots * k * sizeof(int)));
   HIP_TRY(ix->w_part_cnt.ensure((size_t)chunk * nslots * sizeof(int)));
   HIP_TRY(ix->w_thr.ensure((size_t)chunk * sizeof(unsigned)));
+  if (pl.cost_order) {
+    HIP_TRY(ix->w_qorder.ensure((size_t)chunk * sizeof(int)));
+    HIP_TRY(ix->w_cost.ensure((size_t)chunk * sizeof(unsigned long long)));
+  }
   if (pl.defer_units > 0) {
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)DEFER_CAP * sizeof(vaq::DeferRec)));
     HIP_TRY(ix->w_part_d.ensure((size_t)DEFER_CAP * DEFER_SLICES * k * sizeof(float)));
@@ -635,6 +646,11 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bf = pl.bf ? 1 : 0;
     sp.bf_carry = pl.bf_carry;
     sp.bf_pool = pl.bf_pool;
+    if (pl.bf && pl.cost_order && direct && !ti && n >= COST_ORDER_MIN_QUERIES) {
+      HIP_TRY(vaq::launch_cost_order(ix->w_lut.as<float>(), ix->lut_floats, n, ix->sub[0].ncent, ix->bucket_shift,
+                                     ix->w_cost.as<unsigned long long>(), ix->w_qorder.as<int>(), st));
+      sp.qorder = ix->w_qorder.as<int>();
+    }
     const bool defer = pl.bf && pl.defer_units > 0 && direct;
     if (defer) {
       sp.defer_units = pl.defer_units;
@@ -650,6 +666,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       vaq::ScanParams s2 = sp;
       s2.defer_units = 0;
       s2.defer_mode = 1;
+      s2.qorder = nullptr;
       s2.nq = DEFER_CAP;
       s2.n_slices = DEFER_SLICES;
       const int step2 = vaq::scan_wg_step_rows(ix->layout, ix->M);
@@ -1455,6 +1472,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     ix->opt_group = (int)value;
   } else if (k == "best_first") {
     ix->opt_bf = value != 0;
+  } else if (k == "cost_order") {
+    ix->opt_cost_order = value != 0;
   } else if (k == "defer_units") {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
