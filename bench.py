@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--seed-frac", type=int, default=0, help="pre-pass scans N / this many rows (0 = default 64)")
     ap.add_argument("--hot", type=int, default=-1, help="best-first buckets per workgroup (0..32, -1 = default)")
     ap.add_argument("--bf", type=int, default=-1, help="best-first scan form on/off (-1 = library default)")
+    ap.add_argument("--cost-order", type=int, default=-1, help="expensive queries first (one best-first workgroup per "
+                                                               "query): 0 / 1, -1 = library default")
     ap.add_argument("--defer", type=int, default=-1, help="work units of a query's first round before the rest goes to a "
                                                           "second launch (0 = off, -1 = library default)")
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
@@ -428,6 +430,8 @@ def main():
         v.set_option("best_first", args.bf)
     if args.defer >= 0:
         v.set_option("defer_units", args.defer)
+    if args.cost_order >= 0:
+        v.set_option("cost_order", args.cost_order)
     info = v.info()
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the

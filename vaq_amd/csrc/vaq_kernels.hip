@@ -627,28 +627,37 @@ hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, 
 // with its most expensive workgroups; started first they end inside the bulk (C2 scan 0.75 -> 0.55 ms
 // with this predictor, 0.50 with the exact costs: tools/exp_cost_predictor.py).  What makes a
 // query expensive is the number of buckets in its reach, i.e. how FLAT its first lookup table is
-// near the minimum: cost key = (16th smallest - smallest) of the per-bucket minima of table 0,
+// near the minimum: cost key = (16th smallest - smallest) of the per-bucket minima of table 0 (of 256
+// of them, evenly spaced, when there are more),
 // ascending (Spearman 0.65 with a workgroup's lifetime, 0.79 with its steps).
 //   query_cost_kernel   one wave per query -> key bits << 32 | query
 //   cost_sort_kernel    one workgroup: counting sort by the key's top bits -> order[b] = query of block b
 // Block b serves order[b]: blocks are dealt round-robin over the XCDs and dispatched in order, so
 // every XCD gets every 8th query of the ranking.  Speed only: any order is correct.
 // ---------------------------------------------------------------------------
+template <int NREG>  // per-bucket minima a lane holds: buckets at the level of the first code <= 64 NREG
 __global__ __launch_bounds__(256) void query_cost_kernel(const float *__restrict__ lut, int lut_floats, int nq, int n0,
                                                          int shift, unsigned long long *__restrict__ keys) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
   const float *l = lut + (size_t)q * lut_floats;
-  const int nb = n0 >> shift;  // buckets at the level of the first code (<= 1024: 16 per lane)
-  unsigned v[16];
-  unsigned vmin = 0xffffffffu;
+  // (more than 256 buckets at the level of the first code: every stride-th one is sampled -- the
+  //  statistic is a ranking aid, and reading a 4096-entry table per query costs more than it saves)
+  const int nb_all = n0 >> shift;
+  const int stride = nb_all > 64 * NREG ? nb_all / (64 * NREG) : 1;
+  const int nb = nb_all / stride;
+  unsigned v[NREG];
+  unsigned vmin = 0xffffffffu, vmax = 0u;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int i = 0; i < NREG; i++) {
     const int b = i * 64 + lane;
     unsigned m = 0xffffffffu;  // (absent or NaN: never counted)
     if (b < nb) {
-      for (int c = b << shift; c < ((b + 1) << shift); c++) {
+      // (sampled in runs of one 64-byte line of the table, so that the unsampled lines are never read)
+      const int g = (16 >> shift) > 0 ? (16 >> shift) : 1;
+      const int bb = (b / g) * g * stride + (b % g);
+      for (int c = bb << shift; c < ((bb + 1) << shift); c++) {
         const float x = l[c];
         const unsigned xb = x == x ? float_to_bits(x) : 0xffffffffu;  // entries are >= 0: bit order == value order
         m = xb < m ? xb : m;
@@ -656,20 +665,24 @@ __global__ __launch_bounds__(256) void query_cost_kernel(const float *__restrict
     }
     v[i] = m;
     vmin = m < vmin ? m : vmin;
+    vmax = (m != 0xffffffffu && m > vmax) ? m : vmax;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned x = (unsigned)__shfl_xor((int)vmin, o);
+    const unsigned x = (unsigned)__shfl_xor((int)vmin, o), y = (unsigned)__shfl_xor((int)vmax, o);
     vmin = x < vmin ? x : vmin;
+    vmax = y > vmax ? y : vmax;
   }
-  const int J = nb < 16 ? nb : 16;
-  unsigned lo = vmin, hi = 0x7f800000u;  // smallest t with count(v <= t) >= J
-  if (vmin > hi) lo = hi;
+  int J = 16 / stride;
+  J = J < 2 ? 2 : J;
+  J = nb < J ? nb : J;
+  unsigned lo = vmin, hi = vmax;  // smallest t with count(v <= t) >= J (vmax: all of them, unless NaNs leave fewer)
+  if (lo > hi) lo = hi;
   while (lo < hi) {
     const unsigned mid = lo + ((hi - lo) >> 1);
     int c = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) c += __popcll(__ballot(v[i] <= mid));
+    for (int i = 0; i < NREG; i++) c += __popcll(__ballot(v[i] <= mid));
     if (c >= J) hi = mid;
     else lo = mid + 1u;
   }
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(QORDER_THREADS) void cost_sort_kernel(const unsigne
 hipError_t launch_cost_order(const float *lut, int lut_floats, int nq, int n0, int shift, unsigned long long *keys,
                              int *order, hipStream_t st) {
   if (nq <= 0 || nq > QORDER_MAX || (n0 >> shift) > 1024 || (n0 >> shift) < 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(query_cost_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, lut, lut_floats, nq, n0, shift, keys);
+  hipLaunchKernelGGL(query_cost_kernel<4>, dim3((nq + 3) / 4), dim3(256), 0, st, lut, lut_floats, nq, n0, shift, keys);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cost_sort_kernel, dim3(1), dim3(QORDER_THREADS), 0, st, keys, nq, order);

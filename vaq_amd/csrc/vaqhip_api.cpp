@@ -73,7 +73,7 @@ constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than t
 // with 24 (tools/exp_lpt_oracle.py has the cost statistics).  Kept as an option; -1 = the automatic
 // rule below, which no default selects.
 // (launch_cost_order pays from about one residency of workgroups on: 7 per CU)
-constexpr int COST_ORDER_MIN_QUERIES = 2048;
+constexpr int COST_ORDER_MIN_QUERIES = 1024;
 constexpr int DEFER_MIN_QUERIES = 4096, DEFER_UNITS = 96, DEFER_SLICES = 2, DEFER_CAP = 2048;
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
 constexpr int64_t BUCKET_MIN_ROWS_10 = 1900;   // ... before it takes a tenth key bit
@@ -620,6 +620,12 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
                                 k, 0, 0, nullptr, nullptr, ix->w_thr.as<unsigned>(),
                                 ix->w_ms_d.as<float>(), ix->w_ms_id.as<int>(), st));
     }
+    // (the ranking of the queries counts as a pre-pass in the timing: "seed_ms")
+    if (pl.bf && pl.cost_order && pl.n_slices == 1 && ix->N > 0 && !ti && n >= COST_ORDER_MIN_QUERIES) {
+      HIP_TRY(vaq::launch_cost_order(ix->w_lut.as<float>(), ix->lut_floats, n, ix->sub[0].ncent, ix->bucket_shift,
+                                     ix->w_cost.as<unsigned long long>(), ix->w_qorder.as<int>(), st));
+      sp.qorder = ix->w_qorder.as<int>();
+    }
     if (timing) HIP_TRY(hipEventRecord(ev[3], st));
     sp.n_slices = pl.n_slices;
     sp.slice_rows = pl.slice_rows;
@@ -646,11 +652,6 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bf = pl.bf ? 1 : 0;
     sp.bf_carry = pl.bf_carry;
     sp.bf_pool = pl.bf_pool;
-    if (pl.bf && pl.cost_order && direct && !ti && n >= COST_ORDER_MIN_QUERIES) {
-      HIP_TRY(vaq::launch_cost_order(ix->w_lut.as<float>(), ix->lut_floats, n, ix->sub[0].ncent, ix->bucket_shift,
-                                     ix->w_cost.as<unsigned long long>(), ix->w_qorder.as<int>(), st));
-      sp.qorder = ix->w_qorder.as<int>();
-    }
     const bool defer = pl.bf && pl.defer_units > 0 && direct;
     if (defer) {
       sp.defer_units = pl.defer_units;
