@@ -312,6 +312,12 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       bound, work units handed to its waves by ticket, and stops at the first
  *                       bucket out of reach ("best-first form"); 0: the
  *                       16-hot-buckets-then-natural-order form.  Results are identical.
+ *   "cost_order"        1 (default): with one best-first workgroup per query and at least 1024
+ *                       queries in the call, the queries are ranked by a cost key (how flat the
+ *                       first lookup table is near its minimum) and the expensive ones are
+ *                       dispatched first -- a query's cost spans 6x and a launch otherwise ends
+ *                       with its few most expensive workgroups; 0: block b serves query b.
+ *                       Results are written to the queries' own rows and are identical.
  *   "defer_units"       0 (default) = off; n > 0: with one best-first workgroup per query, a
  *                       query's first round takes at most n work units (64 wave steps each); the
  *                       buckets still in reach after it are scanned by a second launch, two

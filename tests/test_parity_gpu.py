@@ -744,3 +744,29 @@ def test_best_first_deferred_queries(vaqlib, oracle, bits, k):
     assert handed[1] >= handed[2] >= handed[8] >= 1, handed
     assert handed[-1] == -1, handed            # the automatic rule: fewer than 4096 queries, not deferring
     v.close()
+
+
+@pytest.mark.parametrize("bits", [[8] * 8, [12, 10, 9, 8, 8, 7, 6, 4], [4] * 8], ids=["m8", "nonuniform", "ties"])
+def test_cost_ordered_dispatch_is_invisible(vaqlib, oracle, bits):
+    """Expensive queries first ("cost_order", on by default from 1024 queries with one best-first
+    workgroup per query): block b serves the b-th query of a ranking by how flat its first lookup
+    table is.  Results land in the queries' own rows and are bit-identical with the ranking off."""
+    N, nq, k = 150_000, 3000, 20
+    c = make_case(8200 + len(bits), 4 * len(bits), bits, N, nq, dup_frac=0.02, integer=(bits[0] == 4))
+    c["X"][7] = np.nan                      # a query without a valid table ranks last, and still gets its row
+    c["X"][11] = c["X"][12]                 # identical queries: identical keys
+    v = make_index(c)
+    v.set_option("timing", 1)
+    v.set_option("cost_order", 0)
+    off = v.search(c["X"], k)
+    assert v.last_timing()["best_first"] == 1 and v.last_timing()["slices"] == 1
+    v.set_option("cost_order", 1)
+    on = v.search(c["X"], k)
+    assert np.array_equal(on.labels, off.labels) and np.array_equal(on.distances.view(np.uint32), off.distances.view(np.uint32))
+    Xp = oracle.project(c["X"][:32], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=max(bits), projected=True)
+    ad = oracle_all_dists(oracle, c, Xp)
+    good = [i for i in range(32) if i != 7]
+    assert_topk_matches(on.labels.reshape(nq, k)[good], on.distances.reshape(nq, k)[good], o_lab[good], o_dis[good], ad[good],
+                        what="ranked dispatch")
+    v.close()

@@ -429,7 +429,10 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int total = p.nq * p.n_slices;
-  const int v = xcd_virtual_id(blockIdx.x, gridDim.x);
+  // One workgroup per query on a cache-resident database: nothing is gained by giving an XCD a
+  // contiguous range of queries (C2 without the ranking: 0.74 ms; block b -> query b: 0.69 ms); with
+  // several slices per query the workgroups of a slice share its rows through their XCD's L2.
+  const int v = (p.n_slices == 1 && p.defer_mode == 0) ? (int)blockIdx.x : xcd_virtual_id(blockIdx.x, gridDim.x);
   if (!p.qorder && v >= total) return;
   // (second launch of a deferring scan, ScanParams::defer_mode: the query comes from defer_list)
   const bool defer2 = p.defer_mode != 0;
