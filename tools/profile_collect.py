@@ -34,8 +34,8 @@ cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
 waves = c["SQ_WAVES"]
 bound = {"c2": {
     "kernel": C2,
-    "bound": "latency of dependent per-workgroup phases + a straggler tail (cache-resident, bucket-pruned scan: "
-             "no HBM roofline applies, and neither the VALUs nor the LDS pipe are saturated)",
+    "bound": "instruction issue + latency of the per-workgroup phases (cache-resident, bucket-pruned scan: no HBM "
+             "roofline applies; VALUs about half busy, LDS pipe a third, 5.6 of 7 resident waves per SIMD on average)",
     "source": "profiles/r02_default_final_pmc_scan.txt (rocprofv3 --pmc passes of `python3 bench.py --steps 20 "
               "--warmup 5`, tools/profile_default.sh + tools/profile_collect.py)",
     "kernel_cycles": round(cycles),
@@ -53,7 +53,9 @@ bound = {"c2": {
     "note": "SQ_* cycle counters are quad-cycles; FETCH_SIZE is doubled per the gfx950 rule for 16-B/lane loads "
             "(MI355X_MICROARCH.md, HBM).  Earlier kernels for the same workload: round 1 (scan_bytes_kernel<8,1,1>, "
             "1.47 ms) 12.6 k VALU + 10.7 k SALU per wave, VALU busy 0.56, wait share 0.56, 5.3 waves per SIMD; round 2 "
-            "before the prefetch fix (1.00 ms) 6.5 k + 6.4 k, VALU busy 0.42, wait share 0.56, 3.5 waves per SIMD",
+            "before the prefetch fix (1.00 ms) 6.5 k + 6.4 k, VALU busy 0.42, wait share 0.56, 3.5 waves per SIMD; with "
+            "the prefetch fix but before expensive queries were dispatched first (0.72 ms) VALU busy 0.42, 4.2 waves "
+            "per SIMD",
 }}
 json.dump(bound, open(os.path.join(dst, "r02_bound.json"), "w"), indent=1)
 s = vals[STREAM]
