@@ -59,6 +59,8 @@ while time.time() - t0 < budget:
         bits[int(np.argmax(bits))] -= 1
     N = int(rng.choice([1, 63, 64, 65, 500, 4097, 20000, 150000]))
     nq = int(rng.choice([1, 2, 3, 7, 33]))
+    if N <= 20000 and rng.integers(0, 12) == 0:
+        nq = 1100  # (from 1024 queries on, one-workgroup-per-query launches rank the queries by cost)
     k = int(rng.choice([1, 5, 64, 100, 128, 129, 500]))
     c = make_case(int(rng.integers(1 << 30)), D, bits, N, nq, dup_frac=float(rng.choice([0, 0.05, 0.5])),
                   integer=bool(rng.integers(0, 4) == 0), rotate=bool(rng.integers(0, 2)))
@@ -82,7 +84,8 @@ while time.time() - t0 < budget:
                     slices=int(rng.choice([0, 0, 1, 2, 5, 300])), hot_buckets=int(rng.choice([0, 3, 16, 32])),
                     waves_per_workgroup=int(rng.choice([0, 4, 8, 16])), seed_thresholds=int(rng.integers(0, 2)),
                     ordered_slices=int(rng.integers(0, 2)), best_first=int(rng.integers(0, 3) > 0),
-                    group_queries=int(rng.choice([0, 1, 2, 2])))
+                    group_queries=int(rng.choice([0, 1, 2, 2])), cost_order=int(rng.integers(0, 2)),
+                    defer_units=int(rng.choice([0, 0, 0, 1, 4])))
         for key, val in opts.items():
             v.set_option(key, val)
         v.set_option("timing", 1)
@@ -103,7 +106,8 @@ while time.time() - t0 < budget:
             print("timing/plan of the failing search:", v.last_timing(), v.info())
             # which option matters: flip each one back to its default in turn
             for key2, dflt in (("best_first", 0), ("best_first", 1), ("ordered_slices", 0), ("slices", 0), ("seed_thresholds", 0),
-                               ("hot_buckets", 16), ("waves_per_workgroup", 0), ("queries_per_pass", 1), ("group_queries", 0)):
+                               ("hot_buckets", 16), ("waves_per_workgroup", 0), ("queries_per_pass", 1), ("group_queries", 0),
+                               ("cost_order", 0), ("defer_units", 0)):
                 v.set_option(key2, dflt)
                 b2 = v.search(c["X"], k)
                 same = np.array_equal(b2.distances.reshape(nq, k), o_dis)
