@@ -38,10 +38,10 @@ namespace vaq {
 #define VAQ_BF_FLUSH 16
 #endif
 #ifndef VAQ_BF_BOOT
-#define VAQ_BF_BOOT 4
+#define VAQ_BF_BOOT 2  // (with the ranked dispatch: 4 / 2 / 1 steps C2 0.546 / 0.539 / 0.697 ms, C3 1.085 / 0.990 / 1.217)
 #endif
 #ifndef VAQ_BF_RING
-#define VAQ_BF_RING 5
+#define VAQ_BF_RING 3  // (3 / 4 / 5 measure the same once the steps wait for vmcnt(RING - 1); 3 leaves registers)
 #endif
 // Issue priority of a wave (s_setprio): the per-workgroup phases in which the other waves of the
 // workgroup wait at a barrier or have nothing to do -- setup, bootstrap, ordering a round's
