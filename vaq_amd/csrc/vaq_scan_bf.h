@@ -523,7 +523,13 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const const_int_ptr bstart_k = (const_int_ptr)(uintptr_t)p.bucket_start;
   const int nwaves = nthreads >> 6;
   const int bs_first = tid < K0 ? bstart[tid] : 0, be_first = tid < K0 ? bstart[tid + 1] : 0;
-  for (int e = tid; e < lut_entries; e += nthreads) lut[e] = glut[e];
+  if (((lut_entries | p.lut_floats) & 3) == 0) {  // (16-byte loads: a quarter of the instructions for the same bytes)
+    const float4 *__restrict__ g4 = reinterpret_cast<const float4 *>(glut);
+    float4 *l4 = reinterpret_cast<float4 *>(lut);
+    for (int e = tid; e < (lut_entries >> 2); e += nthreads) l4[e] = g4[e];
+  } else {
+    for (int e = tid; e < lut_entries; e += nthreads) lut[e] = glut[e];
+  }
   Pol pol;
   pol.init(p, lut, pol_words, tid, nthreads);  // (its LDS tables are complete after the barriers below)
   if (tid == 0) {

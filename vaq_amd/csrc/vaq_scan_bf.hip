@@ -8,7 +8,10 @@ namespace vaq {
 #ifndef VAQ_BF_VGPRS
 #define VAQ_BF_VGPRS 72  // (informative: waves_per_eu(7, 8) below is what enforces it)
 #endif
-#define VAQ_BF_VGPR_CAP __attribute__((amdgpu_waves_per_eu(7, 8)))
+#ifndef VAQ_BF_WAVES_PER_SIMD
+#define VAQ_BF_WAVES_PER_SIMD 7
+#endif
+#define VAQ_BF_VGPR_CAP __attribute__((amdgpu_waves_per_eu(VAQ_BF_WAVES_PER_SIMD, 8)))
 template <int M, bool UL0>
 __global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS VAQ_BF_VGPR_CAP void scan_bytes_bf_kernel(ScanParams p) {
   scan_bf_body<BfBytes<M>, UL0>(p);

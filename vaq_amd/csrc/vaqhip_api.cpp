@@ -60,6 +60,10 @@ struct DevBuf {
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
+#ifndef VAQ_BF_WAVES_PER_SIMD
+#define VAQ_BF_WAVES_PER_SIMD 7
+#endif
+constexpr int BF_WAVES_PER_CU = 4 * VAQ_BF_WAVES_PER_SIMD;  // what the best-first kernels' register budget admits
 constexpr size_t LDS_GRANULE = 1280;           // allocation unit assumed when counting resident workgroups
 constexpr int QUERY_CHUNK = 16384;             // queries per internal launch set
 constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than this
@@ -302,7 +306,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       const int wgs = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)(32 / nw));
       // the largest k-min pool that keeps that many workgroups resident (LDS is handed out in
       // LDS_GRANULE pieces; at 72 VGPRs a SIMD holds 7 waves, so 4-wave workgroups stop at 7)
-      const size_t budget = LDS_LIMIT / (size_t)std::min(wgs, std::max(1, 28 / nw)) / LDS_GRANULE * LDS_GRANULE;
+      const size_t budget = LDS_LIMIT / (size_t)std::min(wgs, std::max(1, BF_WAVES_PER_CU / nw)) / LDS_GRANULE * LDS_GRANULE;
       int pool = pool_lo;
       while (pool + 64 <= pool_hi &&
              vaq::scan_bf_lds_bytes(ix->layout, ix->M, entries, pool + 64, nw, ix->n_buckets, carry) <= budget)
