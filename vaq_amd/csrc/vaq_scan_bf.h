@@ -1183,11 +1183,12 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   if (p.stats && lane == 0)
     for (int i = 0; i < ST_N; i++) atomicAdd(&p.stats[i], cx.st[i]);
 #endif
-  // wave 0 cuts the pool to exactly the k best (ties cut by label); the waves then share the ordering
+  // wave 0 cuts a long pool to exactly the k best (ties cut by label); the waves then share the ordering
   if (wave == 0) {
     const int n0 = (int)sel.hdr[SEL_NCAND];
     PH_MARK(8);
-    if (n0 > k) pool_compact(sel, n0, k, cap, cap, lane);  // (leaves the new count in the header)
+    // (up to BF_RANK_SORT_MAX rows are ranked as they are, the k first written: no cut needed)
+    if (n0 > k && n0 > BF_RANK_SORT_MAX) pool_compact(sel, n0, k, cap, cap, lane);  // (leaves the new count in the header)
     PH_MARK(9);
   }
   __syncthreads();
@@ -1225,7 +1226,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
           const unsigned long long kj = ((unsigned long long)float_to_bits(sel.d[j]) << 32) | (unsigned)sel.id[j];
           rank += kj < ki ? 1 : 0;
         }
-        if (valid) emit(rank, di, ii);
+        if (valid && rank < k) emit(rank, di, ii);
       }
       if (wave == nwaves - 1)
         for (int i = n + lane; i < k; i += 64) emit(i, INFINITY, ID_SENTINEL);
