@@ -314,7 +314,8 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       16-hot-buckets-then-natural-order form.  Results are identical.
  *   "cost_order"        1 (default): with one best-first workgroup per query and at least 1024
  *                       queries in the call, the queries are ranked by a cost key (how flat the
- *                       first lookup table is near its minimum) and the expensive ones are
+ *                       first lookup table is near its minimum: sum of its 16 smallest bucket
+ *                       minima - 16 x the smallest) and the expensive ones are
  *                       dispatched first -- a query's cost spans 6x and a launch otherwise ends
  *                       with its few most expensive workgroups; 0: block b serves query b.
  *                       Results are written to the queries' own rows and are identical.

@@ -14,6 +14,7 @@ from vaq_amd import harness
 dev = torch.device("cuda", 0)
 v, _, cents, _ = bench.build_index([8] * 8, 1_000_000, 0, 1_000_000, dev, 0, 1, 0, iters=15)
 v.set_option("group_queries", 0)
+v.set_option("cost_order", 0)  # (the library's own ranking off: block b serves query b of the batch as given)
 v.set_option("defer_units", 0)
 q = harness.sift_like(10_000, 128, stream=7, device=dev)
 
@@ -74,11 +75,10 @@ for tail_frac, hard_q in ((0.3, 0.85), (0.3, 0.7), (0.5, 0.8), (0.2, 0.9)):
 # [x G/8, (x+1) G/8) in that order), so a sorted order gives ONE XCD all the expensive queries.
 # Longest-first done properly: rank r goes to XCD r % 8, position r // 8.
 def xcd_place(order):
-    G8 = len(order) // 8
-    out = np.empty_like(order)
-    r = np.arange(len(order))
-    out[(r % 8) * G8 + r // 8] = order
-    return out
+    # (block b serves query b of a single-slice best-first launch since the ranked dispatch went in;
+    #  before, XCD x served the contiguous range [x G/8, (x+1) G/8) and this function dealt a
+    #  ranking over the XCDs)
+    return order
 print("longest first, dealt over the XCDs: %.4f ms" % scan_ms(q[torch.from_numpy(xcd_place(order)).to(dev)].contiguous()))
 print("shortest first, dealt over the XCDs: %.4f ms" % scan_ms(q[torch.from_numpy(xcd_place(order[::-1].copy())).to(dev)].contiguous()))
 for pct in (1, 3, 10, 30):

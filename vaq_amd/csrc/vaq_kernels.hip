@@ -627,9 +627,9 @@ hipError_t launch_query_order(const float *lut, int lut_floats, int nq, int n0, 
 // with its most expensive workgroups; started first they end inside the bulk (C2 scan 0.75 -> 0.55 ms
 // with this predictor, 0.50 with the exact costs: tools/exp_cost_predictor.py).  What makes a
 // query expensive is the number of buckets in its reach, i.e. how FLAT its first lookup table is
-// near the minimum: cost key = (16th smallest - smallest) of the per-bucket minima of table 0 (of 256
-// of them, evenly spaced, when there are more),
-// ascending (Spearman 0.65 with a workgroup's lifetime, 0.79 with its steps).
+// near the minimum: cost key = (sum of the 16 smallest - 16 x the smallest) of the per-bucket minima of
+// table 0 (of 256 of them, sampled, when there are more),
+// ascending (Spearman 0.72 with a workgroup's lifetime, 0.83 with its steps).
 //   query_cost_kernel   one wave per query -> key bits << 32 | query
 //   cost_sort_kernel    one workgroup: counting sort by the key's top bits -> order[b] = query of block b
 // Block b serves order[b]: blocks are dealt round-robin over the XCDs and dispatched in order, so
@@ -686,8 +686,21 @@ __global__ __launch_bounds__(256) void query_cost_kernel(const float *__restrict
     if (c >= J) hi = mid;
     else lo = mid + 1u;
   }
-  const float spread = bits_to_float(lo) - bits_to_float(vmin < 0x7f800000u ? vmin : 0x7f800000u);
-  const unsigned kb = spread == spread ? float_to_bits(spread) : 0x7f800000u;  // (>= 0; inf - inf: last)
+  // key = sum of the J smallest minima - J x the smallest: how flat the table is near its minimum
+  // (tools/exp_cost_predictor.py: the batch in this order 0.532 ms, by the J-th smallest alone 0.556)
+  float part = 0.0f;
+  int below = 0;
+#pragma unroll
+  for (int i = 0; i < NREG; i++) {
+    const bool lt = v[i] < lo;
+    part += lt ? bits_to_float(v[i]) : 0.0f;
+    below += __popcll(__ballot(lt));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  const float v0 = bits_to_float(vmin < 0x7f800000u ? vmin : 0x7f800000u);
+  const float spread = (part + (float)(J - below) * bits_to_float(lo)) - (float)J * v0;
+  const unsigned kb = (spread == spread && spread >= 0.0f) ? float_to_bits(spread) : (spread < 0.0f ? 0u : 0x7f800000u);  // (inf - inf: last)
   if (lane == 0) keys[q] = ((unsigned long long)kb << 32) | (unsigned)q;
 }
 
