@@ -769,4 +769,14 @@ def test_cost_ordered_dispatch_is_invisible(vaqlib, oracle, bits):
     good = [i for i in range(32) if i != 7]
     assert_topk_matches(on.labels.reshape(nq, k)[good], on.distances.reshape(nq, k)[good], o_lab[good], o_dis[good], ad[good],
                         what="ranked dispatch")
+    # more queries than one internal launch takes (16384): every chunk is ranked on its own
+    big = np.tile(c["X"], (6, 1))[:17000]
+    v.set_option("timing", 0)
+    on_big = v.search(big, k)
+    v.set_option("cost_order", 0)
+    off_big = v.search(big, k)
+    assert np.array_equal(on_big.labels, off_big.labels)
+    assert np.array_equal(on_big.distances.view(np.uint32), off_big.distances.view(np.uint32))
+    sel = [i for i in range(3000) if i != 7]
+    assert np.array_equal(on_big.labels.reshape(17000, k)[3000:6000][sel], on.labels.reshape(nq, k)[sel])
     v.close()

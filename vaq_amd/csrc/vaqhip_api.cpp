@@ -325,7 +325,8 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       if (s == 1 && k <= 256 && (ix->opt_defer > 0 || (ix->opt_defer < 0 && nq >= DEFER_MIN_QUERIES)))
         pl->defer_units = ix->opt_defer > 0 ? ix->opt_defer : DEFER_UNITS;
       // more queries than workgroups resident at a time: start the expensive ones first
-      pl->cost_order = s == 1 && ix->opt_cost_order && nq >= COST_ORDER_MIN_QUERIES && nq <= QUERY_CHUNK &&
+      // (calls of more than QUERY_CHUNK queries are served chunk by chunk, each ranked on its own)
+      pl->cost_order = s == 1 && ix->opt_cost_order && nq >= COST_ORDER_MIN_QUERIES &&
                        (ix->sub[0].ncent >> ix->bucket_shift) <= 1024;
       pl->nwaves = bnw;
       pl->lds = blds;
