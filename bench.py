@@ -209,11 +209,27 @@ def build_index(bits, N, lo, hi, dev, device_index, world, rank, iters, random_c
     return v, host_codes, cents, ti_info
 
 
-def settle(run_step, seconds=0.3):
+def settle(run_step, seconds=0.3, world=1, device=None):
     """Part of setup, untimed: the index build frees several GB of staging memory and the
     driver reclaims it asynchronously -- a one-off 40-60 ms stall of the GPU queue lands some
     milliseconds later (tools/step_times.py; INTEGRATION.md "first search after set_codes").
-    Run the step until `seconds` have passed so that it is not mistaken for a step time."""
+    Run the step until `seconds` have passed so that it is not mistaken for a step time.
+    With several ranks the step contains a collective, so every rank must run it the SAME number
+    of times: the count is agreed on (max over the ranks) after one measured step -- a loop that
+    each rank ends by its own clock leaves one rank waiting in an all-gather nobody else enters."""
+    if world > 1:
+        import torch.distributed as dist
+        sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+        t = time.perf_counter()
+        run_step()
+        sync()
+        dt = max(time.perf_counter() - t, 1e-4)
+        n = torch.tensor([int(min(500, max(1, seconds / dt)))], dtype=torch.int64, device=device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        for _ in range(int(n.item())):
+            run_step()
+            sync()
+        return
     t = time.perf_counter()
     while time.perf_counter() - t < seconds:
         run_step()
@@ -471,7 +487,7 @@ def main():
         f"replicas={replicas} info={info}")
 
     # ---------------------------------------------------------------- timed --
-    settle(run_step)
+    settle(run_step, world=world if collective else 1, device=dev)
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()

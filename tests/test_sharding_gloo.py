@@ -171,3 +171,34 @@ def test_shard_bounds():
             assert spans[0][0] == 0 and spans[-1][1] == N
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(hi >= lo for lo, hi in spans)
+
+
+def _settle_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import bench
+    calls = [0]
+
+    def step():  # a step with a collective in it, much slower on one rank than on the other
+        time.sleep(0.002 if rank == 0 else 0.011)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        calls[0] += 1
+
+    bench.settle(step, seconds=0.1, world=world)
+    ret[rank] = calls[0]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_settle_runs_the_same_steps_on_every_rank():
+    """bench.py's settle loop contains the all-gather of the N > 1 path: ranks that ended it by their
+    own clocks ran it different numbers of times and one of them hung in the collective (seen in a
+    2-rank rehearsal).  The count is now agreed on; both ranks must report the same number."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_settle_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0] == ret[1] and ret[0] >= 2, dict(ret)
