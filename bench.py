@@ -548,6 +548,9 @@ def main():
         "queries_per_pass": tm["queries_per_pass"], "passes": passes,
         "other_kernels_ms": {"project": round(tm["project_ms"], 4), "lut_build": round(tm["lut_ms"], 4),
                              "threshold_seed": round(tm["seed_ms"], 4), "merge": round(tm["merge_ms"], 4)},
+        "pre_pass_note": "threshold_seed = whatever runs between the table build and the scan: the threshold pre-pass "
+                         "of streamed databases, or the ranking of the queries by cost (query_cost_kernel + "
+                         "cost_sort_kernel) where one best-first workgroup serves each query",
         "slices": tm["slices"], "workgroups": tm["workgroups"], "lds_bytes": tm["lds_bytes"],
         "effective_per_query_GBps": round(eff, 1),
         "effective_note": "rows x code bytes x queries / kernel time: counts rows pruned unread and rows "
