@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VAQHIP_VERSION 102
+#define VAQHIP_VERSION 103
 
 /* error codes */
 #define VAQHIP_OK            0
@@ -330,6 +330,18 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       effect when the codes are (re)set
  *   "bucket_skip"       1 (default); 0 visits every bucket -- for measuring the streaming
  *                       rate of the scan, results are the same                             */
+/*   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 512
+ *                       queries in the call, the best-first pass is cut after each query's nearest
+ *                       buckets and what is left in reach is scanned bucket by bucket: a bucket's
+ *                       rows are streamed once for ALL the queries that still want it, four
+ *                       queries' lookup tables at a time in LDS, instead of once per query
+ *                       ("Bucket-major second pass"); 0: off; 2: whenever a
+ *                       kernel exists (tests).  Results are identical.
+ *   "bm_candidates"     slots of a query's candidate buffer in that pass (default 2048); a query that
+ *                       overflows it is finished by the best-first form
+ *   "bm_units"          work units (64 wave steps) of the first pass per query; 0 = about one
+ *                       average bucket
+ *   "bm_queries_per_group", "bm_waves"   launch shape of the second pass (0 = default 4 / 16)    */
 int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
 
 typedef struct {
@@ -348,6 +360,7 @@ typedef struct {
   int best_first;                              /* 1: the best-first form ("best_first" option) ran */
   int deferred_queries;                        /* queries of the last search cut in two ("defer_units"): handed
                                                   to the second launch; -1 = the search did not defer */
+  int bucket_major;                            /* 1: the bucket-major second pass ran ("bucket_major") */
 } vaqhip_timing;
 int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out);
 

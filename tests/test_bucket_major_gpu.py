@@ -1,0 +1,127 @@
+"""GPU parity of the bucket-major second pass (vaq_amd/csrc/vaq_scan_bm.hip; option
+"bucket_major"): after a capped best-first pass every bucket still in some query's reach is
+streamed once for all the queries that want it.  Checked against the CPU oracle
+(VAQ::searchHeap's restatement) under the tie contract of helpers.assert_topk_matches, and
+bit for bit against the library's own one-workgroup-per-query form: the result is the k
+smallest (distance, label) pairs whatever order the rows are met in."""
+import numpy as np
+import pytest
+
+from helpers import assert_topk_matches, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def make_index(c, bucket_bits=0):
+    import vaq_amd
+    v = vaq_amd.VaqHip()
+    v.mBitsAlloc = list(c["bits"])
+    v.mCentroidsPerSubs = c["cents"]
+    v.mEigenVectors = c["eig"]
+    if bucket_bits:
+        v._ensure_index()
+        v.set_option("bucket_bits", bucket_bits)
+    v.mCodebook = c["codes"]
+    return v
+
+
+def oracle_all_dists(oracle, c, Xp):
+    out = []
+    for q in range(Xp.shape[0]):
+        lut = oracle.create_lut(Xp[q], c["cents"], max(c["bits"]))
+        out.append(oracle.all_dists(lut, c["codes"]))
+    return np.stack(out)
+
+
+def run(v, X, k, **opts):
+    for key, val in opts.items():
+        v.set_option(key, val)
+    a = v.search(X, k)
+    nq = X.shape[0]
+    return a.labels.reshape(nq, k).copy(), a.distances.reshape(nq, k).copy(), v.last_timing()
+
+
+CASES = [
+    # seed, bits, N, nq, k, bucket_bits, make_case kwargs
+    (9101, [8] * 16, 400_000, 96, 100, 0, {}),
+    (9102, [8] * 8, 300_000, 70, 10, 0, {"dup_frac": 0.05}),
+    (9103, [8] * 16, 300_000, 33, 100, 10, {"dup_frac": 0.02}),   # key continues into the second code
+    (9104, [8] * 32, 260_000, 18, 37, 9, {}),                      # rows re-read in the tail (no carried words)
+    (9105, [8] * 8, 500_000, 130, 1, 9, {}),
+]
+
+
+@pytest.mark.parametrize("seed,bits,N,nq,k,bb,kw", CASES, ids=[f"m{len(c[1])}_n{c[2] // 1000}k_k{c[4]}_b{c[5]}" for c in CASES])
+def test_bucket_major_matches_oracle(vaqlib, oracle, seed, bits, N, nq, k, bb, kw):
+    c = make_case(seed, 8 * len(bits) if len(bits) <= 16 else 4 * len(bits), bits, N, nq, **kw)
+    c["X"][3] = np.nan  # a query without a valid table: all -1 (VAQ.cpp:1750: FLT_MAX > NaN is false)
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=8)
+    ad = oracle_all_dists(oracle, c, Xp[:24])
+    v = make_index(c, bb)
+    v.set_option("timing", 1)
+    base_l, base_d, t0 = run(v, c["X"], k, bucket_major=0)
+    assert t0["bucket_major"] == 0
+    assert_topk_matches(base_l[:24], base_d[:24], o_lab[:24], o_dis[:24], ad, what="one workgroup per query")
+    seen = 0
+    for units, cap, qb, nw in [(0, 0, 0, 0), (1, 0, 4, 16), (1, 0, 2, 8), (4, 0, 4, 4), (1, 8, 4, 16), (2, 64, 2, 16),
+                               (100000, 0, 0, 0)]:
+        l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=units, bm_candidates=cap, bm_queries_per_group=qb, bm_waves=nw)
+        seen += t["bucket_major"]
+        what = f"units={units} cap={cap} qb={qb} nw={nw}"
+        assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)), what
+        assert np.array_equal(l, base_l), what
+        assert np.all(l[3] == -1)
+    assert seen == 7
+    assert np.array_equal(base_d.view(np.uint32)[np.arange(nq) != 3], o_dis.view(np.uint32)[np.arange(nq) != 3])
+    v.close()
+
+
+def test_bucket_major_overflow_and_small_k(vaqlib, oracle):
+    """Fewer than k rows within reach of pass A (k close to the rows of a bucket), candidate
+    buffers of 1 slot (every query overflows and is finished by the best-first form), N < k."""
+    bits = [8] * 8
+    c = make_case(9201, 64, bits, 280_000, 40, dup_frac=0.3, integer=True)  # small integers: massive ties
+    Xp = oracle.project(c["X"], c["eig"])
+    for k in (256, 100):
+        o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=8)
+        v = make_index(c)
+        v.set_option("timing", 1)
+        base_l, base_d, _ = run(v, c["X"], k, bucket_major=0)
+        for cap in (1, 0):
+            l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=cap)
+            assert t["bucket_major"] == 1
+            assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l), (k, cap)
+        assert np.array_equal(base_d.view(np.uint32), o_dis.view(np.uint32))
+        v.close()
+
+
+def test_bucket_major_encoded_clustered(vaqlib, oracle):
+    """Rows encoded from clustered SIFT-shaped vectors (real pruning: a query reaches a few per cent
+    of the buckets), 1500 queries so that the automatic plan's shape is exercised: cost-ordered pass
+    A, several groups per bucket, work stealing at the end."""
+    import torch
+    from vaq_amd import harness
+    N, nq, k = 1_500_000, 1500, 100
+    bits = [8] * 16
+    base = harness.sift_like(N, 128, stream=0, device="cuda")
+    Xq = harness.sift_like(nq, 128, stream=1, device="cuda")
+    E = harness.pca_eigenvectors(base[:200_000])
+    Ed = E.to("cuda")
+    cents = harness.train_codebooks((base[:100_000] @ Ed), bits, iters=8)
+    codes = harness.encode_torch(base @ Ed, cents).cpu().numpy().view(np.uint16)
+    c = dict(bits=bits, cents=cents, eig=E.numpy(), codes=codes, X=Xq.cpu().numpy())
+    del base
+    torch.cuda.empty_cache()
+    v = make_index(c, 10)
+    v.set_option("timing", 1)
+    base_l, base_d, t0 = run(v, c["X"], k, bucket_major=0)
+    l, d, t = run(v, c["X"], k, bucket_major=2)
+    assert t["bucket_major"] == 1 and t0["bucket_major"] == 0
+    assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32))
+    assert np.array_equal(l, base_l)
+    Xp = oracle.project(c["X"][:48], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=16)
+    ad = oracle_all_dists(oracle, c, Xp)
+    assert_topk_matches(l[:48], d[:48], o_lab, o_dis, ad, what="encoded, bucket-major")
+    v.close()

@@ -54,7 +54,8 @@ class Timing(C.Structure):
                 ("merge_ms", C.c_float), ("n_searches", C.c_int), ("queries_per_pass", C.c_int), ("slices", C.c_int),
                 ("workgroups", C.c_int), ("passes", C.c_int), ("lds_bytes", C.c_int),
                 ("seed_slices", C.c_int), ("early_abandon", C.c_int),
-                ("best_first", C.c_int), ("deferred_queries", C.c_int)]
+                ("best_first", C.c_int), ("deferred_queries", C.c_int),
+                ("bucket_major", C.c_int)]
 
 
 class MultiInfo(C.Structure):

@@ -103,6 +103,11 @@ struct ScanParams {
   int defer_units, defer_mode, defer_cap;
   unsigned *defer_count;  // entries asked for so far (beyond defer_cap: not handed over, scanned in place)
   struct DeferRec *defer_list;
+  // bucket-major second pass (vaq_scan_bm.hip): with defer_units > 0 and bm_done set, EVERY query whose
+  // capped first round left buckets in reach stores its done_key here (preset 0xffffffff = nothing
+  // left) and its threshold -- lowered to its exact k-th distance when it has k rows -- in g_thr,
+  // instead of joining defer_list
+  unsigned *bm_done;
   int bf;                 // 1: best-first form (vaq_scan_bf.h): all buckets of the slice in ascending order
                           //    of their bound, work units by ticket (needs qb == 1, ea == EA_QUEUE, no TI)
   int ti;                 // 1: TI form
@@ -195,6 +200,64 @@ hipError_t launch_merge(const float *part_d, const int *part_id, const int *part
                         int64_t list_stride, int64_t query_stride, int nq, int k,
                         int64_t id_base, int in_final, int32_t *labels, float *dist,
                         unsigned *thr_out, float *scratch_d, int *scratch_id, hipStream_t st);
+
+// ---- bucket-major second pass of a streamed database with many queries (vaq_scan_bm.hip) ----
+// After a capped best-first first pass (ScanParams::bm_done) every query knows the buckets it has
+// finished (keys <= done_key) and an upper bound of its k-th distance (g_thr).  What is left in
+// reach is turned round: per BUCKET the list of the queries that still want it, and workgroups
+// that stream a bucket's rows once for QB queries whose lookup tables sit interleaved in LDS --
+// the groups of one bucket run back to back on one XCD, so the bucket comes from HBM once and from
+// that XCD's L2 for everybody else.  Survivors (complete sum not above the query's threshold) are
+// appended to a per-query candidate buffer; a per-query histogram of the appended distances moves
+// the shared threshold.  bm_select then takes the k best of (first pass list + candidates); a
+// query whose buffer overflowed goes to the defer list and is finished by the best-first form.
+constexpr int BM_HIST_BINS = 64;
+constexpr int BM_XCDS = 8;
+struct BmParams {
+  const uint32_t *codes;
+  const uint32_t *perm;      // sorted row -> label, or nullptr = identity
+  const int *bucket_start;   // [n_buckets + 1]
+  int n_buckets, bucket_t;   // bucket = first code << bucket_t | top bucket_t bits of the second (bucket_shift == 0)
+  int M;
+  const float *lut;          // [nq][lut_floats]
+  int lut_floats;
+  int nq, k, qb;
+  int nwaves;
+  unsigned *g_thr;           // [nq] float bits: thresholds (rows AT them stay admissible)
+  const unsigned *done_key;  // [nq]
+  // plan (device, written by launch_bm_plan)
+  unsigned *mask;            // [nq][n_buckets / 32] buckets still in reach
+  int *cnt;                  // [n_buckets] queries per bucket
+  int *qoff;                 // [n_buckets + 1]
+  int *fill;                 // [n_buckets]
+  int *qlist;                // [nq * n_buckets] (worst case) queries of bucket b at qoff[b]
+  int *border;               // [n_buckets] buckets by descending work
+  int *ioff;                 // [BM_XCDS][n_buckets / BM_XCDS + 2] prefix of the work items of each XCD's buckets
+  unsigned *tickets;         // [BM_XCDS]
+  // candidates
+  int cap;                   // slots per query
+  float *cand_d;             // [nq][cap]
+  int *cand_id;              // [nq][cap] labels (without id_base)
+  unsigned *cand_cnt;        // [nq] candidates appended (beyond cap: not stored -> overflow)
+  unsigned *hist;            // [nq][BM_HIST_BINS]
+  float *scale;              // [nq] bins / H, 0 = histogram off
+  // first-pass results (the API's format) and the final output, in place
+  int32_t *labels;           // [nq][k]
+  float *dist;
+  int64_t id_base;
+  // overflow -> defer list
+  unsigned *defer_count;
+  struct DeferRec *defer_list;
+  int defer_cap;
+};
+bool scan_bm_supported(int layout, int M, int n_buckets, int bucket_shift, int seq, int k);
+size_t scan_bm_lds_bytes(int M, int qb, int nwaves);
+// words of the plan arrays above, for the caller's allocation: mask, cnt + qoff + fill + border + ioff + tickets
+size_t bm_plan_small_words(int n_buckets);
+// mark + count, order + prefix, fill (three launches)
+hipError_t launch_bm_plan(const BmParams &p, hipStream_t st);
+hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st);
+hipError_t launch_bm_select(const BmParams &p, hipStream_t st);
 
 // ---- triangle-inequality cluster pruning (vaq_ti.hip) ----------------------
 // packed index rows -> uint16 N x M in original row order (inverse of launch_pack_codes)

@@ -867,6 +867,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   //      is rarely anything but the check that nothing is left ----
   bool first_round = !defer2;
   bool defer_tried = false;
+  bool bm_handed = false;  // (bucket-major second pass follows: publish the exact k-th distance)
   unsigned done_key = rec_done;  // buckets with keys <= done_key are finished (after the first round)
   for (;;) {
     BF_PRIO_SERIAL();
@@ -903,23 +904,34 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       // keeping the launch waiting for this one (a full list: scan on here).
       defer_tried = true;
       if (tid == 0) {
-        const unsigned idx = atomicAdd(p.defer_count, 1u);
-        const bool ok = idx < (unsigned)p.defer_cap;
-        if (ok) {
-          DeferRec rec;
-          rec.q = qi;
-          rec.done_key = done_key;
-          rec.thr = sel.hdr[SEL_THR_D];
-          rec.pad = 0;
-          p.defer_list[idx] = rec;
-          p.g_thr[qi] = rec.thr;  // the word the second launch's workgroups of this query share
+        bool ok;
+        if (p.bm_done) {
+          // bucket-major second pass (vaq_scan_bm.hip): every query hands over, no list
+          p.bm_done[qi] = done_key;
+          atomicMin(&p.g_thr[qi], sel.hdr[SEL_THR_D]);  // (lowered to the exact k-th distance below)
+          ok = true;
+        } else {
+          const unsigned idx = atomicAdd(p.defer_count, 1u);
+          ok = idx < (unsigned)p.defer_cap;
+          if (ok) {
+            DeferRec rec;
+            rec.q = qi;
+            rec.done_key = done_key;
+            rec.thr = sel.hdr[SEL_THR_D];
+            rec.pad = 0;
+            p.defer_list[idx] = rec;
+            p.g_thr[qi] = rec.thr;  // the word the second launch's workgroups of this query share
+          }
         }
         sh_rot[0] = ok ? 1u : 0u;
       }
       __syncthreads();
       const bool handed = sh_rot[0] != 0u;
       __syncthreads();
-      if (handed) break;
+      if (handed) {
+        bm_handed = p.bm_done != nullptr;
+        break;
+      }
     }
     STAT_ADD(ST_FOLDS, n);
 #ifdef VAQ_WGTIME
@@ -1227,6 +1239,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
           rank += kj < ki ? 1 : 0;
         }
         if (valid && rank < k) emit(rank, di, ii);
+        if (bm_handed && valid && rank == k - 1) atomicMin(&p.g_thr[qi], float_to_bits(di));
       }
       if (wave == nwaves - 1)
         for (int i = n + lane; i < k; i += 64) emit(i, INFINITY, ID_SENTINEL);
@@ -1241,6 +1254,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       wave_lds_sync();
       bitonic_sort<false>(sel.d, sel.id, P, lane, 64);  // ascending by (distance, label)
       for (int i = lane; i < k; i += 64) emit(i, sel.d[i], sel.id[i]);
+      if (bm_handed && lane == 0 && n >= k) atomicMin(&p.g_thr[qi], float_to_bits(sel.d[k - 1]));
     }
     if (!p.final_labels && tid == 0) p.part_cnt[(size_t)out_q * p.n_slices + slice] = n < k ? n : k;
   }

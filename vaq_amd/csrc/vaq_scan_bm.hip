@@ -1,0 +1,633 @@
+// vaq_scan_bm.hip -- the bucket-major second pass of the early-abandon scan (VAQ::searchEarlyAbandon,
+// VAQ.cpp:1694-1727; results identical to VAQ::searchHeap, :1729-1758) for a database that is
+// streamed from HBM by MANY queries at once (BASELINE configs C4 / C5: 100M-1B rows, 10 k queries).
+//
+// The best-first form (vaq_scan_bf.h) gives every query its own workgroup, which streams the
+// buckets in that query's reach: 10 k queries x 3 % of 1B rows x 16 B = 5 TB through the memory
+// fabric for a 16 GB code array, and nothing is shared between the ~300 queries that read the same
+// bucket.  Here the work is turned round:
+//   pass A  (vaq_scan_bf.h, ScanParams::bm_done) every query scans its nearest buckets, a capped
+//           number of work units; it leaves its k best so far in the result arrays, the buckets it
+//           has finished (done_key) and its k-th distance as a threshold (g_thr).
+//   plan    bm_mark_kernel   per query: the buckets still in reach (bound <= threshold, key >
+//                            done_key: the SAME key the best-first form orders by), one mask bit
+//                            each, counted per bucket; the query's histogram starts from pass A's rows
+//           bm_order_kernel  buckets by descending work (rows x query groups), dealt to the eight
+//                            XCD queues; prefix of the work items of each queue; list offsets
+//           bm_fill_kernel   per bucket the list of its queries
+//   pass B  scan_bm_kernel   persistent workgroups, one queue per XCD.  A work item = (bucket,
+//                            group of QB queries): the QB lookup tables are staged in LDS interleaved
+//                            per entry (one ds_read_b128 serves four queries), the bucket's rows are
+//                            streamed once for the group, all groups of a bucket run back to back on
+//                            the same XCD so that its rows come from HBM once and from that L2 after.
+//                            Phases A / A2 / survivor queue / tail are the best-first form's, per
+//                            (row, query).  A row whose complete sum is not above its query's
+//                            threshold is APPENDED to that query's candidate buffer (one global
+//                            atomic), and counted in the query's 64-bin histogram over [0, H]: the
+//                            upper edge of the bin where the running count reaches k has >= k real
+//                            rows at or below it -- a valid threshold for everybody (g_thr).
+//   select  bm_select_kernel per query: k best of (pass A's list + candidates), ascending by
+//                            (distance, label); a query whose buffer overflowed is handed to the
+//                            best-first form's second launch (ScanParams::defer_mode), which scans
+//                            its remaining buckets on its own and merges (launch_defer_merge).
+// Nothing depends on the order in which candidates arrive: the result is the k smallest (distance,
+// label) pairs of the rows, as VAQ::searchHeap's is (DESIGN.md "Ties" for equal distances).
+// Arithmetic per row: dism = l0; dism += l1; dism += l2; dism += l3; dist (+)= dism, group by group
+// (VAQ.cpp:1737-1748).
+#include "vaq_scan_bf.h"
+
+namespace vaq {
+
+constexpr int BM_QCAP = 128;          // survivor queue of a wave: at most 63 left over + 64 pushed
+#ifndef VAQ_BM_RING
+#define VAQ_BM_RING 3
+#endif
+constexpr int BM_RING = VAQ_BM_RING;  // code items in flight per wave
+constexpr int BM_THR_EVERY = 16;      // wave steps between reads of the workgroup's thresholds (LDS)
+constexpr int BM_THR_GLOBAL_EVERY = 64;  // ... and between wave 0's reads of the shared words
+constexpr int BM_TRIGGER = 8;         // every this many candidates of a query its histogram is read
+constexpr int BM_MAX_THREADS = 1024;
+
+__host__ __device__ inline int bm_ioff_stride(int n_buckets) { return n_buckets / BM_XCDS + 2; }
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+// One workgroup per query.  The bucket key is scan_bf_body's bucket_key_of for one slice covering
+// every row (r0 = 0, r1 = n_rows) and bucket_shift == 0, bit for bit: pass A's done_key is compared
+// with it.
+__global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
+  __shared__ unsigned gmin[1 << GMIN_MAX_BITS];
+  __shared__ unsigned smask[BF_MAX_BUCKETS / 32];
+  __shared__ unsigned shist[BM_HIST_BINS];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int K0 = p.n_buckets, bt = p.bucket_t;
+  const int nwords = K0 / 32;
+  const unsigned done = p.done_key[q];
+  if (tid == 0) p.cand_cnt[q] = 0u;
+  if (tid < BM_HIST_BINS) shist[tid] = 0u;
+  if (tid < nwords) smask[tid] = 0u;
+  const unsigned thr_bits = p.g_thr[q];
+  const float H = bits_to_float(thr_bits);
+  const float scale = (done != 0xffffffffu && H > 0.0f && H < FLT_MAX) ? (float)BM_HIST_BINS / H : 0.0f;
+  if (done != 0xffffffffu) {  // (wave-uniform: pass A left buckets in reach)
+    const float *__restrict__ l = p.lut + (size_t)q * p.lut_floats;
+    if (bt > 0) {
+      if (tid < (1 << bt)) gmin[tid] = 0x7f800000u;
+      __syncthreads();
+      const int ncent1 = 256;
+      const int w = 8 - bt;  // log2 of the group size
+      const int seg = w < 6 ? 1 << w : 64;
+      for (int e0 = tid - lane; e0 < ncent1; e0 += blockDim.x) {
+        const int e = e0 + lane;
+        unsigned v = e < ncent1 ? float_to_bits(l[256 + e]) : 0x7f800000u;
+        for (int o = 1; o < seg; o <<= 1) {
+          const unsigned x = (unsigned)__shfl_xor((int)v, o);
+          v = x < v ? x : v;
+        }
+        if ((lane & (seg - 1)) == 0 && e < ncent1) atomicMin(&gmin[e >> w], v);
+      }
+    }
+    __syncthreads();
+    const unsigned idx_mask = (unsigned)K0 - 1u;  // (K0 is a power of two >= 16)
+    const unsigned empty_key = ~idx_mask;
+    for (int b = tid; b < K0; b += blockDim.x) {
+      const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
+      if (be <= bs) continue;
+      float m;
+      if (bt > 0) {
+        m = l[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
+      } else {
+        const float x = l[b];
+        m = x < INFINITY ? x : INFINITY;
+      }
+      if (!(m == m)) continue;
+      const unsigned key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;
+      if ((key & empty_key) != empty_key && key > done && (key & ~idx_mask) <= thr_bits) {
+        atomicOr(&smask[b >> 5], 1u << (b & 31));
+        atomicAdd(&p.cnt[b], 1);
+      }
+    }
+    // the rows pass A found are the first entries of the histogram
+    if (scale != 0.0f) {
+      for (int i = tid; i < p.k; i += blockDim.x) {
+        if (p.labels[(size_t)q * p.k + i] >= 0) {
+          const unsigned bin = (unsigned)(p.dist[(size_t)q * p.k + i] * scale);
+          atomicAdd(&shist[bin < BM_HIST_BINS - 1 ? bin : BM_HIST_BINS - 1], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < nwords) p.mask[(size_t)q * nwords + tid] = smask[tid];
+  if (tid < BM_HIST_BINS) p.hist[(size_t)q * BM_HIST_BINS + tid] = shist[tid];
+  if (tid == 0) p.scale[q] = scale;
+}
+
+// One workgroup of 1024 threads: thread b owns bucket b.
+__global__ __launch_bounds__(BM_MAX_THREADS) void bm_order_kernel(BmParams p) {
+  __shared__ unsigned long long keys[BF_MAX_BUCKETS];
+  __shared__ int pre[BF_MAX_BUCKETS];
+  const int tid = threadIdx.x, K0 = p.n_buckets, QB = p.qb;
+  const int c = tid < K0 ? p.cnt[tid] : 0;
+  const long long rows = tid < K0 ? (long long)p.bucket_start[tid + 1] - p.bucket_start[tid] : 0;
+  const long long G = (c + QB - 1) / QB;
+  const unsigned long long work = (unsigned long long)(rows > 0 ? rows : 0) * (unsigned long long)G;  // < 2^44
+  keys[tid] = tid < K0 ? ((((1ull << 44) - 1ull - work) << 10) | (unsigned)tid) : ~0ull;
+  pre[tid] = c;
+  __syncthreads();
+  // buckets by descending work (ties by bucket)
+  for (int size = 2; size <= BF_MAX_BUCKETS; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (tid < BF_MAX_BUCKETS / 2) {
+        const int i = 2 * tid - (tid & (stride - 1));
+        const int j = i + stride;
+        const unsigned long long a = keys[i], d = keys[j];
+        if ((a > d) == ((i & size) == 0)) { keys[i] = d; keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  if (tid < K0) p.border[tid] = (int)(keys[tid] & 1023ull);
+  // inclusive prefix of the per-bucket query counts
+  for (int o = 1; o < BF_MAX_BUCKETS; o <<= 1) {
+    const int v = tid >= o ? pre[tid - o] : 0;
+    __syncthreads();
+    pre[tid] += v;
+    __syncthreads();
+  }
+  if (tid < K0) {
+    p.qoff[tid + 1] = pre[tid];
+    p.fill[tid] = 0;
+  }
+  if (tid == 0) p.qoff[0] = 0;
+  // XCD x works through the buckets at positions x, x + 8, ... of the order: prefix of their items
+  if (tid < BM_XCDS) {
+    const int stride = bm_ioff_stride(K0);
+    const int nb = (K0 - tid + BM_XCDS - 1) / BM_XCDS;
+    int acc = 0;
+    for (int j = 0; j < nb; j++) {
+      p.ioff[tid * stride + j] = acc;
+      const int b = (int)(keys[tid + BM_XCDS * j] & 1023ull);
+      acc += (p.cnt[b] + QB - 1) / QB;
+    }
+    p.ioff[tid * stride + nb] = acc;
+    p.tickets[tid] = 0u;
+  }
+}
+
+// One wave per query: lane w owns word w of the query's bucket mask.
+__global__ __launch_bounds__(64) void bm_fill_kernel(BmParams p) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int nwords = p.n_buckets / 32;
+  if (lane >= nwords) return;
+  unsigned bits = p.mask[(size_t)q * nwords + lane];
+  while (bits) {
+    const int b = lane * 32 + __builtin_ctz(bits);
+    bits &= bits - 1u;
+    const int pos = atomicAdd(&p.fill[b], 1);
+    p.qlist[p.qoff[b] + pos] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass B
+// ---------------------------------------------------------------------------
+template <int QB> struct BmVec;
+template <> struct BmVec<2> { typedef f32x2 T; };
+template <> struct BmVec<4> { typedef f32x4 T; };
+
+__host__ __device__ inline size_t bm_lds_bytes(int M, int qb, int nwaves) {
+  const int qcw = M <= 16 ? M / 4 - 1 : 0;
+  return (size_t)M * 256 * qb * 4 + (size_t)nwaves * BM_QCAP * 4 * (3 + qcw);
+}
+
+template <int M, int QB>
+__global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
+  typedef BfBytesItem<M, (M < 16 ? 16 : M)> Item;
+  typedef typename BmVec<QB>::T VT;
+  constexpr int ROWS = Item::ROWS;
+  constexpr int WPR = M / 4;
+  constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
+  constexpr int WSTEP = 64 * ROWS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_ioff[BF_MAX_BUCKETS / BM_XCDS + 2];
+  __shared__ int s_ticket;
+  __shared__ unsigned s_thr[QB];
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  float *lut = reinterpret_cast<float *>(smem);  // entry (t * 256 + c) of query i at (t * 256 + c) * QB + i
+  unsigned char *wb = smem + (size_t)M * 256 * QB * 4 + (size_t)wave * BM_QCAP * 4 * (3 + QCW);
+  int *q_row = reinterpret_cast<int *>(wb);
+  float *q_part = reinterpret_cast<float *>(q_row + BM_QCAP);
+  int *q_i = reinterpret_cast<int *>(q_part + BM_QCAP);
+  uint32_t *q_cw = reinterpret_cast<uint32_t *>(q_i + BM_QCAP);
+  const int K0 = p.n_buckets, bt = p.bucket_t, k = p.k;
+  const uint32_t *__restrict__ codes = p.codes;
+  const uint32_t *__restrict__ perm = p.perm;
+  const int stride = bm_ioff_stride(K0);
+  const int home = (int)(blockIdx.x & (BM_XCDS - 1));  // (workgroups are dealt round-robin over the XCDs)
+
+  for (int hop = 0; hop < BM_XCDS; hop++) {
+    // the home queue first; when it is empty, the others' leftovers (their buckets then come through
+    // this XCD's L2 as well: a second copy, at the very end of the launch only)
+    const int xq = (home + hop) & (BM_XCDS - 1);
+    const int nb = (K0 - xq + BM_XCDS - 1) / BM_XCDS;
+    __syncthreads();
+    for (int i = tid; i <= nb; i += nthreads) s_ioff[i] = p.ioff[xq * stride + i];
+    __syncthreads();
+    const int total = s_ioff[nb];
+    for (;;) {
+      __syncthreads();  // the previous item is finished by every wave
+      if (tid == 0) s_ticket = (int)atomicAdd(&p.tickets[xq], 1u);
+      __syncthreads();
+      const int t = s_ticket;
+      if (t >= total) break;  // (every thread: the same t)
+      int lo = 0, hi = nb;  // s_ioff[lo] <= t < s_ioff[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_ioff[mid] <= t) lo = mid;
+        else hi = mid;
+      }
+      const int b = p.border[xq + BM_XCDS * lo];
+      const int g = t - s_ioff[lo];
+      const int nact_all = p.cnt[b] - g * QB;
+      const int nact = nact_all < QB ? nact_all : QB;  // >= 1
+      const int qbase = p.qoff[b] + g * QB;
+      int qi[QB];
+#pragma unroll
+      for (int i = 0; i < QB; i++) qi[i] = __builtin_amdgcn_readfirstlane(p.qlist[qbase + (i < nact ? i : 0)]);
+      const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
+      // ---- the group's lookup tables, interleaved per entry ----
+      {
+        const float4 *g4[QB];
+#pragma unroll
+        for (int i = 0; i < QB; i++) g4[i] = reinterpret_cast<const float4 *>(p.lut + (size_t)qi[i] * p.lut_floats);
+        for (int e4 = tid; e4 < M * 64; e4 += nthreads) {
+          float4 v[QB];
+#pragma unroll
+          for (int i = 0; i < QB; i++) v[i] = g4[i][e4];
+          VT *dst = reinterpret_cast<VT *>(lut) + (size_t)e4 * 4;
+          VT o0, o1, o2, o3;
+#pragma unroll
+          for (int i = 0; i < QB; i++) {
+            o0[i] = v[i].x;
+            o1[i] = v[i].y;
+            o2[i] = v[i].z;
+            o3[i] = v[i].w;
+          }
+          dst[0] = o0;
+          dst[1] = o1;
+          dst[2] = o2;
+          dst[3] = o3;
+        }
+      }
+      if (tid < QB) {
+        int myq = qi[0];
+#pragma unroll
+        for (int j = 1; j < QB; j++) myq = tid == j ? qi[j] : myq;
+        s_thr[tid] = tid < nact ? __hip_atomic_load(&p.g_thr[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0xbf800000u;  // -1: nothing passes (a slot past the end of the bucket's list)
+      }
+      __syncthreads();
+
+      // ---- per-wave state ----
+      float thr[QB], l0[QB];
+#pragma unroll
+      for (int i = 0; i < QB; i++) {
+        thr[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)s_thr[i]));
+        l0[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[(size_t)(b >> bt) * QB + i])));
+      }
+      int qcnt = 0;
+
+      auto pick_q = [&](const int i) -> int {
+        int q = qi[0];
+#pragma unroll
+        for (int j = 1; j < QB; j++) q = i == j ? qi[j] : q;
+        return q;
+      };
+      auto pick_thr = [&](const int i) -> float {
+        float x = thr[0];
+#pragma unroll
+        for (int j = 1; j < QB; j++) x = i == j ? thr[j] : x;
+        return x;
+      };
+      auto refresh = [&](const int kstep) {
+        if ((kstep & (BM_THR_EVERY - 1)) != 0) return;
+        if (wave == 0 && (kstep & (BM_THR_GLOBAL_EVERY - 1)) == 0 && kstep > 0) {
+          if (lane < nact) {
+            const unsigned gt = __hip_atomic_load(&p.g_thr[pick_q(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMin(&s_thr[lane], gt);
+          }
+          wave_lds_sync();
+        }
+#pragma unroll
+        for (int i = 0; i < QB; i++) {
+          const unsigned tb = __hip_atomic_load(&s_thr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          thr[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)tb));
+        }
+      };
+
+      // a row whose complete sum is not above its query's threshold: one more candidate of that query
+      auto append = [&](const float d, const int row, const int i, const bool ok) {
+        if (__ballot(ok) == 0ull) return;
+        int q = 0;
+        float sc = 0.0f;
+        bool trig = false;
+        if (ok) {
+          q = pick_q(i);
+          const int label = perm ? (int)perm[row] : row;  // labels are ORIGINAL rows
+          const unsigned pos = atomicAdd(&p.cand_cnt[q], 1u);
+          sc = p.scale[q];
+          if (sc != 0.0f) {
+            const unsigned bin = (unsigned)(d * sc);
+            atomicAdd(&p.hist[(size_t)q * BM_HIST_BINS + (bin < BM_HIST_BINS - 1 ? bin : BM_HIST_BINS - 1)], 1u);
+          }
+          if (pos < (unsigned)p.cap) {
+            p.cand_d[(size_t)q * p.cap + pos] = d;
+            p.cand_id[(size_t)q * p.cap + pos] = label;
+          }
+          trig = sc != 0.0f && ((pos + 1u) & (BM_TRIGGER - 1)) == 0u;
+        }
+        // (rare path: wait for its loads here, or the wait-count bookkeeping of every block it
+        //  rejoins degrades to "all loads" -- vaq_scan_bf.h, flush())
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        unsigned long long m = __ballot(trig);
+        while (m != 0ull) {
+          // the query's histogram: the upper edge of the bin where the running count reaches k has
+          // at least k rows (pass A's and appended ones: distinct rows) at or below it
+          const int src = __builtin_ctzll(m);
+          m &= m - 1ull;
+          const int qq = __builtin_amdgcn_readlane(q, src);
+          const int ii = __builtin_amdgcn_readlane(i, src);
+          const float scq = bits_to_float((unsigned)__builtin_amdgcn_readlane((int)float_to_bits(sc), src));
+          int inc = (int)__hip_atomic_load(&p.hist[(size_t)qq * BM_HIST_BINS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(inc, o);
+            if (lane >= o) inc += x;
+          }
+          const unsigned long long reach = __ballot(inc >= k);
+          if (reach != 0ull) {
+            const int jb = __builtin_ctzll(reach);
+            if (jb < BM_HIST_BINS - 1) {  // (the last bin also holds everything beyond H)
+              const float edge = ((float)(jb + 1) / scq) * (1.0f + 1.0f / 1048576.0f);
+              if (lane == 0) {
+                atomicMin(&p.g_thr[qq], float_to_bits(edge));
+                atomicMin(&s_thr[ii], float_to_bits(edge));
+              }
+            }
+          }
+        }
+      };
+
+      // phase B: the top n (<= 64) queue entries, one per lane: groups 1.. of the row, abandoning
+      // after each (VAQ.cpp:1708)
+      auto drain = [&](const int n) {
+        qcnt -= n;
+        const bool ok = lane < n;
+        const int slot = qcnt + (ok ? lane : 0);
+        const int row = q_row[slot];
+        float acc = q_part[slot];
+        const int i = q_i[slot];
+        const float tl = pick_thr(i);
+        bool alive = ok;
+        uint32_t cw[QCW > 0 ? QCW : 1];
+#pragma unroll
+        for (int w = 0; w < QCW; w++) cw[w] = q_cw[w * BM_QCAP + slot];
+#pragma unroll
+        for (int gq = 1; gq < WPR; gq++) {
+          const uint32_t c4 = QCW > 0 ? cw[gq - 1] : codes[(int64_t)row * WPR + gq];
+          if (alive) {
+            float dism = lut[(size_t)((gq * 4 + 0) * 256 + (c4 & 0xffu)) * QB + i];
+            dism = dism + lut[(size_t)((gq * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)) * QB + i];
+            dism = dism + lut[(size_t)((gq * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)) * QB + i];
+            dism = dism + lut[(size_t)((gq * 4 + 3) * 256 + (c4 >> 24)) * QB + i];
+            acc = acc + dism;  // dist += dism
+            alive = acc <= tl;
+          }
+        }
+        append(acc, row, i, alive);
+      };
+
+      auto step = [&](const Item &cur, const int kstep) {
+        const int base = (bs & ~(WSTEP - 1)) + (wave + kstep * nwaves) * WSTEP;
+        refresh(kstep);
+        const bool interior = base >= bs && base + WSTEP <= be;  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+          const int row = base + lane * ROWS + r;
+          const uint32_t c0 = cur.word(r, 0);
+          const bool in_range = interior || (row >= bs && row < be);
+          // A: dism = l0; dism += l1
+          const VT v1 = *reinterpret_cast<const VT *>(&lut[(size_t)(256 + ((c0 >> 8) & 0xffu)) * QB]);
+          float part[QB];
+          bool alive[QB];
+          bool any = false;
+#pragma unroll
+          for (int i = 0; i < QB; i++) {
+            part[i] = l0[i] + v1[i];
+            alive[i] = in_range && part[i] <= thr[i];
+            any = any || alive[i];
+          }
+          if (__ballot(any) == 0ull) continue;
+          if (any) {  // A2: dism += l2; dism += l3 -> the first group's sum
+            const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
+            const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
+#pragma unroll
+            for (int i = 0; i < QB; i++) {
+              part[i] = part[i] + v2[i];
+              part[i] = part[i] + v3[i];
+              alive[i] = alive[i] && part[i] <= thr[i];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < QB; i++) {
+            const unsigned long long m = __ballot(alive[i]);
+            if (m != 0ull) {
+              const int qp = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+              if (alive[i]) {
+                q_row[qp] = row;
+                q_part[qp] = part[i];
+                q_i[qp] = i;
+#pragma unroll
+                for (int w = 0; w < QCW; w++) q_cw[w * BM_QCAP + qp] = cur.word(r, w + 1);
+              }
+              qcnt += __popcll(m);
+              if (qcnt >= 64) drain(64);
+            }
+          }
+        }
+      };
+
+      // ---- the bucket's rows: wave w takes steps w, w + nwaves, ... (the workgroup streams the
+      //      bucket front to back, as every other group of this bucket does at the same time) ----
+      const int base00 = bs & ~(WSTEP - 1);
+      const int nsteps = (be - base00 + WSTEP - 1) / WSTEP;
+      const int nmine = wave < nsteps ? (nsteps - wave + nwaves - 1) / nwaves : 0;
+      if (nmine > 0) {
+        auto item_of = [&](const int kk) -> int64_t {
+          const int kc = kk < nmine - 1 ? kk : nmine - 1;
+          return (int64_t)((base00 + (wave + kc * nwaves) * WSTEP) / ROWS) + lane;
+        };
+        Item ring[BM_RING];
+#pragma unroll
+        for (int u = 0; u < BM_RING; u++) ring[u].load(codes, item_of(u));
+        int kk = 0;
+        for (; kk + BM_RING <= nmine; kk += BM_RING) {
+#pragma unroll
+          for (int u = 0; u < BM_RING; u++) {
+            step(ring[u], kk + u);
+            ring[u].load(codes, item_of(kk + u + BM_RING));  // (past the end: the last item again, a cache hit)
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < BM_RING; u++)
+          if (kk + u < nmine) step(ring[u], kk + u);
+      }
+      while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// select
+// ---------------------------------------------------------------------------
+// One workgroup per query: the k smallest (distance bits, label) keys of pass A's list and the
+// candidates at or below the final threshold, ascending -- heap_reorder's output order
+// (utils/Heap.hpp:322-349), empty slots -1 / FLT_MAX.
+constexpr int BM_SELECT_THREADS = 256;
+__global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p, int P_max) {
+  extern __shared__ unsigned long long sk[];  // [P_max]
+  __shared__ unsigned s_n;
+  const int q = blockIdx.x, tid = threadIdx.x, k = p.k;
+  const unsigned done = p.done_key[q];
+  if (done == 0xffffffffu) return;  // pass A finished this query: its list is the result
+  const unsigned cnt = p.cand_cnt[q];
+  const unsigned thr = p.g_thr[q];
+  if (cnt > (unsigned)p.cap) {
+    // more candidates than slots: the best-first form finishes this query on its own
+    if (tid == 0) {
+      const unsigned idx = atomicAdd(p.defer_count, 1u);
+      if (idx < (unsigned)p.defer_cap) {
+        DeferRec rec;
+        rec.q = q;
+        rec.done_key = done;
+        rec.thr = thr;
+        rec.pad = 0;
+        p.defer_list[idx] = rec;
+      }
+    }
+    return;
+  }
+  if (tid == 0) s_n = 0u;
+  __syncthreads();
+  for (int i = tid; i < k; i += BM_SELECT_THREADS) {
+    const int32_t lab = p.labels[(size_t)q * k + i];
+    if (lab >= 0)
+      sk[atomicAdd(&s_n, 1u)] = ((unsigned long long)float_to_bits(p.dist[(size_t)q * k + i]) << 32) |
+                                (unsigned)((int64_t)lab - p.id_base);
+  }
+  for (unsigned i = tid; i < cnt; i += BM_SELECT_THREADS) {
+    const unsigned db = float_to_bits(p.cand_d[(size_t)q * p.cap + i]);
+    if (db <= thr)  // (distances are >= 0: bit order == value order; rows AT the threshold stay)
+      sk[atomicAdd(&s_n, 1u)] = ((unsigned long long)db << 32) | (unsigned)p.cand_id[(size_t)q * p.cap + i];
+  }
+  __syncthreads();
+  const int n = (int)s_n;
+  int P = 2;
+  while (P < n) P <<= 1;
+  for (int i = n + tid; i < P; i += BM_SELECT_THREADS) sk[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += BM_SELECT_THREADS) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const unsigned long long a = sk[i], c = sk[j];
+        if ((a > c) == ((i & size) == 0)) { sk[i] = c; sk[j] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < k; i += BM_SELECT_THREADS) {
+    const bool ok = i < n;
+    const unsigned long long key = ok ? sk[i] : 0ull;
+    p.labels[(size_t)q * k + i] = ok ? (int32_t)((int64_t)(int)(unsigned)(key & 0xffffffffull) + p.id_base) : -1;
+    p.dist[(size_t)q * k + i] = ok ? bits_to_float((unsigned)(key >> 32)) : FLT_MAX;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+bool scan_bm_supported(int layout, int M, int n_buckets, int bucket_shift, int seq, int k) {
+  if (layout != LAYOUT_BYTES || (M != 8 && M != 16 && M != 32)) return false;
+  return bucket_shift == 0 && !seq && n_buckets >= 32 && n_buckets <= BF_MAX_BUCKETS &&
+         (n_buckets & (n_buckets - 1)) == 0 && k >= 1 && k <= 1024;
+}
+
+size_t scan_bm_lds_bytes(int M, int qb, int nwaves) { return bm_lds_bytes(M, qb, nwaves); }
+
+size_t bm_plan_small_words(int n_buckets) {
+  // cnt, qoff (+1), fill, border, ioff, tickets
+  return (size_t)n_buckets * 4 + 1 + (size_t)BM_XCDS * bm_ioff_stride(n_buckets) + BM_XCDS;
+}
+
+hipError_t launch_bm_plan(const BmParams &p, hipStream_t st) {
+  if (p.nq <= 0) return hipSuccess;
+  if (p.n_buckets > BF_MAX_BUCKETS || p.n_buckets < 32 || p.bucket_t > GMIN_MAX_BITS || (p.qb != 2 && p.qb != 4))
+    return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(p.cnt, 0, (size_t)p.n_buckets * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bm_mark_kernel, dim3(p.nq), dim3(256), 0, st, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(bm_order_kernel, dim3(1), dim3(BM_MAX_THREADS), 0, st, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(bm_fill_kernel, dim3(p.nq), dim3(64), 0, st, p);
+  return hipGetLastError();
+}
+
+template <typename K>
+static hipError_t launch_bm_kernel(K kernel, const BmParams &p, size_t lds, int grid, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(p.nwaves * 64), lds, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st) {
+  if (p.nq <= 0) return hipSuccess;
+  if (p.nwaves < 1 || p.nwaves > 16) return hipErrorInvalidValue;
+  const size_t lds = bm_lds_bytes(p.M, p.qb, p.nwaves);
+  if (lds + 1024 > 160 * 1024) return hipErrorInvalidValue;
+  // persistent workgroups: as many as are resident at once, a multiple of the XCD count
+  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  const int by_waves = 32 / p.nwaves;
+  per_cu = per_cu < by_waves ? per_cu : by_waves;
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  const int grid = ((n_cu * per_cu + BM_XCDS - 1) / BM_XCDS) * BM_XCDS;
+#define VAQ_BM_CASE(MM)                                                                         \
+  case MM:                                                                                      \
+    return p.qb == 4 ? launch_bm_kernel(scan_bm_kernel<MM, 4>, p, lds, grid, st)                \
+                     : launch_bm_kernel(scan_bm_kernel<MM, 2>, p, lds, grid, st);
+  switch (p.M) {
+    VAQ_BM_CASE(8)
+    VAQ_BM_CASE(16)
+    VAQ_BM_CASE(32)
+  default: return hipErrorInvalidValue;
+  }
+#undef VAQ_BM_CASE
+}
+
+hipError_t launch_bm_select(const BmParams &p, hipStream_t st) {
+  if (p.nq <= 0) return hipSuccess;
+  int P = 2;
+  while (P < p.k + p.cap) P <<= 1;
+  const size_t lds = (size_t)P * sizeof(unsigned long long);
+  if (lds > 128 * 1024) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bm_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bm_select_kernel, dim3(p.nq), dim3(BM_SELECT_THREADS), lds, st, p, P);
+  return hipGetLastError();
+}
+
+} // namespace vaq

@@ -86,6 +86,12 @@ constexpr int64_t SEED_MIN_ROWS = 1 << 21;     // below this a scan is too short
 constexpr int64_t SEED_MIN_SLICES = 256;       // fewer, longer slices warm themselves up
 constexpr int BF_STREAMED_MIN_QUERIES = 128;    // from here on the best-first form also takes streamed databases
 constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to which EA_INPLACE is chosen
+// Bucket-major second pass (vaq_scan_bm.hip): a streamed database and so many queries that every
+// bucket is wanted by several of them.  Pass A (best-first, one workgroup per query) is cut after
+// about one average bucket's worth of work units; BM_CAND_CAP candidate slots per query.
+constexpr int BM_MIN_QUERIES = 512;
+constexpr int BM_CAND_CAP = 2048;
+constexpr int BM_QB = 4, BM_NWAVES = 16;
 
 } // namespace
 
@@ -111,6 +117,8 @@ struct vaqhip_index {
   DevBuf w_q, w_qproj, w_lut, w_part_d, w_part_id, w_part_cnt, w_labels, w_dist, w_stage, w_lutref, w_thr, w_ms_d, w_ms_id, w_order, w_qorder;
   DevBuf w_cost;   // [nq] cost keys of launch_cost_order
   DevBuf w_defer;  // [0] entries asked for, then DEFER_CAP records (best-first form, queries cut in two)
+  // bucket-major second pass: plan arrays, per-bucket query lists, candidates, per-query words
+  DevBuf w_bm_small, w_bm_mask, w_bm_qlist, w_bm_cand_d, w_bm_cand_id, w_bm_query;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
   // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
@@ -120,7 +128,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -158,6 +166,8 @@ struct Plan {
   int bf_pool = 0;
   int defer_units = 0;  // > 0: expensive queries are cut in two (ScanParams::defer_*)
   bool cost_order = false;  // one best-first workgroup per query: expensive queries are dispatched first
+  bool bm = false;          // bucket-major second pass behind a capped best-first pass (vaq_scan_bm.hip)
+  int bm_qb = 0, bm_nwaves = 0, bm_cap = 0;
 };
 
 int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
@@ -189,6 +199,18 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
                            ix->ti_T == 0 && !ix->opt_order &&
                            vaq::scan_bf_supported(ix->layout, ix->M, 1, ea, ix->n_buckets, ix->seq);
   if (bf_streamed) qb = 1;
+  // ... and with MORE queries still, several of them want every bucket: after a capped best-first
+  // pass (one workgroup per query, its nearest buckets) the rest is scanned bucket-major, each
+  // bucket streamed once for all the queries that reach it (vaq_scan_bm.hip)
+  const bool bm = ix->opt_bm && ix->opt_bf && ix->ti_T == 0 && !ix->opt_order && !ix->opt_no_skip && ix->opt_slices <= 1 &&
+                  (ix->opt_qb == 0 || ix->opt_bm == 2) && (ea == vaq::EA_QUEUE || ix->opt_bm == 2) && k <= 256 && ix->N > 0 &&
+                  ((!resident && nq >= BM_MIN_QUERIES) || ix->opt_bm == 2) &&
+                  vaq::scan_bm_supported(ix->layout, ix->M, ix->n_buckets, ix->bucket_shift, ix->seq, k) &&
+                  vaq::scan_bf_supported(ix->layout, ix->M, 1, vaq::EA_QUEUE, ix->n_buckets, ix->seq);
+  if (bm) {
+    qb = 1;
+    ea = vaq::EA_QUEUE;
+  }
   if (nq < qb) qb = nq >= 2 ? 2 : 1;
   // Pick the workgroup size that puts the most wavefronts on a CU: the LUT and
   // the selection state are per workgroup, the survivor queues per wave; a CU
@@ -244,7 +266,8 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
   const int64_t N = ix->N;
   const int nqb = (nq + qb - 1) / qb;
   int64_t s;
-  if (ix->opt_slices > 0) s = ix->opt_slices;
+  if (bm) s = 1;
+  else if (ix->opt_slices > 0) s = ix->opt_slices;
   else {
     // workgroups wanted in flight; the best-first form on a streamed database likes four times as
     // many (shorter workgroups: a query's cost varies tenfold and the launch ends with the longest;
@@ -330,6 +353,18 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
                        (ix->sub[0].ncent >> ix->bucket_shift) <= 1024;
       pl->nwaves = bnw;
       pl->lds = blds;
+      if (bm && s == 1) {
+        pl->bm = true;
+        pl->bm_qb = ix->opt_bm_qb > 0 ? ix->opt_bm_qb : BM_QB;
+        pl->bm_nwaves = ix->opt_bm_nwaves > 0 ? ix->opt_bm_nwaves : BM_NWAVES;
+        pl->bm_cap = ix->opt_bm_cap > 0 ? ix->opt_bm_cap : BM_CAND_CAP;
+        while (vaq::scan_bm_lds_bytes(ix->M, pl->bm_qb, pl->bm_nwaves) + 2048 > LDS_LIMIT && pl->bm_nwaves > 4) pl->bm_nwaves >>= 1;
+        // pass A: about one average bucket per query (a work unit = 64 wave steps)
+        const int64_t unit_rows = 64 * (int64_t)(vaq::scan_wg_step_rows(ix->layout, ix->M) / vaq::SCAN_MAX_WAVES);
+        const int64_t avg = N / ix->n_buckets + 1;
+        pl->defer_units = ix->opt_bm_units > 0 ? ix->opt_bm_units
+                                               : (int)std::min<int64_t>(4096, std::max<int64_t>(8, (avg + unit_rows - 1) / unit_rows));
+      }
     }
   }
   return VAQHIP_OK;
@@ -457,7 +492,21 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     HIP_TRY(ix->w_qorder.ensure((size_t)chunk * sizeof(int)));
     HIP_TRY(ix->w_cost.ensure((size_t)chunk * sizeof(unsigned long long)));
   }
-  if (pl.defer_units > 0) {
+  if (pl.bm) {
+    const size_t K0 = (size_t)ix->n_buckets;
+    HIP_TRY(ix->w_bm_small.ensure(vaq::bm_plan_small_words(ix->n_buckets) * 4));
+    HIP_TRY(ix->w_bm_mask.ensure((size_t)chunk * (K0 / 32) * 4));
+    HIP_TRY(ix->w_bm_qlist.ensure((size_t)chunk * K0 * sizeof(int)));
+    HIP_TRY(ix->w_bm_cand_d.ensure((size_t)chunk * pl.bm_cap * sizeof(float)));
+    HIP_TRY(ix->w_bm_cand_id.ensure((size_t)chunk * pl.bm_cap * sizeof(int)));
+    // per query: done_key, candidate count, scale, histogram
+    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (3 + vaq::BM_HIST_BINS) * 4));
+    // overflowed queries are finished by the best-first form's second launch
+    HIP_TRY(ix->w_defer.ensure(16 + (size_t)chunk * sizeof(vaq::DeferRec)));
+    HIP_TRY(ix->w_part_d.ensure((size_t)chunk * DEFER_SLICES * k * sizeof(float)));
+    HIP_TRY(ix->w_part_id.ensure((size_t)chunk * DEFER_SLICES * k * sizeof(int)));
+    HIP_TRY(ix->w_part_cnt.ensure((size_t)chunk * DEFER_SLICES * sizeof(int)));
+  } else if (pl.defer_units > 0) {
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)DEFER_CAP * sizeof(vaq::DeferRec)));
     HIP_TRY(ix->w_part_d.ensure((size_t)DEFER_CAP * DEFER_SLICES * k * sizeof(float)));
     HIP_TRY(ix->w_part_id.ensure((size_t)DEFER_CAP * DEFER_SLICES * k * sizeof(int)));
@@ -514,6 +563,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.defer_cap = 0;
     sp.defer_count = nullptr;
     sp.defer_list = nullptr;
+    sp.bm_done = nullptr;
     sp.no_skip = ix->opt_no_skip;
     sp.stats = nullptr;
 #if defined(VAQ_STATS) || defined(VAQ_PHASES)
@@ -566,7 +616,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     }
     // shared admission thresholds start at heap_heapify's neutral FLT_MAX (0x7f7fffff); a query
     // served by ONE workgroup and no pre-pass never reads the word (share_thr = 0 below)
-    if (pl.n_slices > 1 || pl.seed_slices > 0)
+    if (pl.n_slices > 1 || pl.seed_slices > 0 || pl.bm)
       HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->w_thr.p), 0x7f7fffff, n, st));
     if (ti) {
       // VAQ::search's TI branch (VAQ.cpp:799-826) then VAQ::searchTriangleInequality (:1540-1692)
@@ -657,7 +707,59 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     sp.bf = pl.bf ? 1 : 0;
     sp.bf_carry = pl.bf_carry;
     sp.bf_pool = pl.bf_pool;
-    const bool defer = pl.bf && pl.defer_units > 0 && direct;
+    const bool bm = pl.bm && pl.bf && direct && !ti;
+    const bool defer = pl.bf && pl.defer_units > 0 && direct && !bm;
+    const int defer_cap = bm ? n : DEFER_CAP;
+    vaq::BmParams bp = {};
+    if (bm) {
+      // pass A: every query's nearest buckets, capped; what is left in reach is handed over
+      unsigned *qw = ix->w_bm_query.as<unsigned>();
+      sp.defer_units = pl.defer_units;
+      sp.defer_cap = defer_cap;
+      sp.defer_count = ix->w_defer.as<unsigned>();
+      sp.defer_list = reinterpret_cast<vaq::DeferRec *>(ix->w_defer.as<unsigned char>() + 16);
+      sp.bm_done = qw;
+      HIP_TRY(hipMemsetAsync(sp.defer_count, 0, sizeof(unsigned), st));
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(qw), 0xffffffffu, n, st));
+      bp.codes = sp.codes;
+      bp.perm = sp.perm;
+      bp.bucket_start = sp.bucket_start;
+      bp.n_buckets = sp.n_buckets;
+      bp.bucket_t = sp.bucket_t;
+      bp.M = ix->M;
+      bp.lut = sp.lut;
+      bp.lut_floats = sp.lut_floats;
+      bp.nq = n;
+      bp.k = k;
+      bp.qb = pl.bm_qb;
+      bp.nwaves = pl.bm_nwaves;
+      bp.g_thr = sp.g_thr;
+      bp.done_key = qw;
+      bp.cand_cnt = qw + (size_t)chunk;
+      bp.scale = reinterpret_cast<float *>(qw + (size_t)2 * chunk);
+      bp.hist = qw + (size_t)3 * chunk;
+      bp.mask = ix->w_bm_mask.as<unsigned>();
+      {
+        int *sm = ix->w_bm_small.as<int>();
+        const int K0 = ix->n_buckets;
+        bp.cnt = sm;
+        bp.qoff = sm + K0;
+        bp.fill = sm + 2 * K0 + 1;
+        bp.border = sm + 3 * K0 + 1;
+        bp.ioff = sm + 4 * K0 + 1;
+        bp.tickets = reinterpret_cast<unsigned *>(sm + vaq::bm_plan_small_words(K0) - vaq::BM_XCDS);
+      }
+      bp.qlist = ix->w_bm_qlist.as<int>();
+      bp.cap = pl.bm_cap;
+      bp.cand_d = ix->w_bm_cand_d.as<float>();
+      bp.cand_id = ix->w_bm_cand_id.as<int>();
+      bp.labels = d_labels + (size_t)q0 * k;
+      bp.dist = d_dist + (size_t)q0 * k;
+      bp.id_base = ix->id_base;
+      bp.defer_count = sp.defer_count;
+      bp.defer_list = sp.defer_list;
+      bp.defer_cap = defer_cap;
+    }
     if (defer) {
       sp.defer_units = pl.defer_units;
       sp.defer_cap = DEFER_CAP;
@@ -666,14 +768,21 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       HIP_TRY(hipMemsetAsync(sp.defer_count, 0, sizeof(unsigned), st));
     }
     if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
-    if (defer) {
+    if (bm) {
+      // plan, pass B, select (vaq_scan_bm.hip); queries whose candidate buffer overflowed join the defer list
+      HIP_TRY(vaq::launch_bm_plan(bp, st));
+      HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
+      HIP_TRY(vaq::launch_bm_select(bp, st));
+    }
+    if (defer || bm) {
       // second launch: what the expensive queries have left, DEFER_SLICES workgroups each (those
       // beyond the list's length return at once), then their lists are merged into the results
       vaq::ScanParams s2 = sp;
       s2.defer_units = 0;
       s2.defer_mode = 1;
+      s2.bm_done = nullptr;
       s2.qorder = nullptr;
-      s2.nq = DEFER_CAP;
+      s2.nq = defer_cap;
       s2.n_slices = DEFER_SLICES;
       const int step2 = vaq::scan_wg_step_rows(ix->layout, ix->M);
       int64_t rows2 = (ix->N + DEFER_SLICES - 1) / DEFER_SLICES;
@@ -685,7 +794,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       s2.final_dist = nullptr;
       int grid2 = 0;
       HIP_TRY(vaq::launch_scan(s2, &grid2, st));
-      HIP_TRY(vaq::launch_defer_merge(sp.defer_count, DEFER_CAP, sp.defer_list, DEFER_SLICES, k, sp.part_d, sp.part_id,
+      HIP_TRY(vaq::launch_defer_merge(sp.defer_count, defer_cap, sp.defer_list, DEFER_SLICES, k, sp.part_d, sp.part_id,
                                       sp.part_cnt, ix->id_base, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st));
     }
 #ifdef VAQ_PHASES
@@ -728,7 +837,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     tm.seed_slices = pl.seed_slices;
     tm.early_abandon = pl.ea;
     tm.best_first = pl.bf ? 1 : 0;
-    tm.deferred_queries = defer ? 0 : -1;
+    tm.deferred_queries = (defer || bm) ? 0 : -1;  // (bucket-major: queries whose candidate buffer overflowed)
+    tm.bucket_major = bm ? 1 : 0;
     tm.queries_per_pass = pl.qb;
     tm.slices = pl.n_slices;
     tm.workgroups = grid;
@@ -1483,6 +1593,21 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "defer_units") {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
+  } else if (k == "bucket_major") {
+    if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "bucket_major must be 0 (off), 1 (automatic) or 2 (whenever a kernel exists)");
+    ix->opt_bm = (int)value;
+  } else if (k == "bm_candidates") {
+    if (value < 0 || value > 4096) return fail(VAQHIP_EINVAL, "bm_candidates must be 0 (default) or 1..4096");
+    ix->opt_bm_cap = (int)value;
+  } else if (k == "bm_units") {
+    if (value < 0 || value > (1 << 20)) return fail(VAQHIP_EINVAL, "bm_units must be 0 (automatic) or a number of work units");
+    ix->opt_bm_units = (int)value;
+  } else if (k == "bm_queries_per_group") {
+    if (value != 0 && value != 2 && value != 4) return fail(VAQHIP_EINVAL, "bm_queries_per_group must be 0, 2 or 4");
+    ix->opt_bm_qb = (int)value;
+  } else if (k == "bm_waves") {
+    if (value != 0 && value != 4 && value != 8 && value != 16) return fail(VAQHIP_EINVAL, "bm_waves must be 0, 4, 8 or 16");
+    ix->opt_bm_nwaves = (int)value;
   } else if (k == "seed_thresholds") {
     ix->opt_seed = value != 0;
   } else if (k == "waves_per_workgroup") {
@@ -1521,7 +1646,7 @@ int vaqhip_last_timing(vaqhip_index *ix, vaqhip_timing *out) {
     if (ix->last.deferred_queries >= 0 && ix->w_defer.p) {  // (the events above are past: the counter is final)
       unsigned asked = 0;
       HIP_TRY(hipMemcpy(&asked, ix->w_defer.p, sizeof asked, hipMemcpyDeviceToHost));
-      ix->last.deferred_queries = (int)std::min<unsigned>(asked, (unsigned)DEFER_CAP);
+      ix->last.deferred_queries = ix->last.bucket_major ? (int)asked : (int)std::min<unsigned>(asked, (unsigned)DEFER_CAP);
     }
   }
   *out = ix->last;
