@@ -213,6 +213,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   __shared__ int s_ioff[BF_MAX_BUCKETS / BM_XCDS + 2];
   __shared__ int s_ticket;
   __shared__ unsigned s_thr[QB];
+  __shared__ int s_q[QB];
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   float *lut = reinterpret_cast<float *>(smem);  // entry (t * 256 + c) of query i at (t * 256 + c) * QB + i
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         }
       }
       if (tid < QB) {
-        int myq = qi[0];
-#pragma unroll
-        for (int j = 1; j < QB; j++) myq = tid == j ? qi[j] : myq;
+        // (per-lane picks among the group's queries and thresholds go through LDS: a register array
+        //  indexed by a lane value ends up in scratch memory)
+        const int myq = p.qlist[qbase + (tid < nact ? tid : 0)];
+        s_q[tid] = myq;
         s_thr[tid] = tid < nact ? __hip_atomic_load(&p.g_thr[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                 : 0xbf800000u;  // -1: nothing passes (a slot past the end of the bucket's list)
       }
@@ -299,17 +301,9 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
       }
       int qcnt = 0;
 
-      auto pick_q = [&](const int i) -> int {
-        int q = qi[0];
-#pragma unroll
-        for (int j = 1; j < QB; j++) q = i == j ? qi[j] : q;
-        return q;
-      };
+      auto pick_q = [&](const int i) -> int { return s_q[i]; };
       auto pick_thr = [&](const int i) -> float {
-        float x = thr[0];
-#pragma unroll
-        for (int j = 1; j < QB; j++) x = i == j ? thr[j] : x;
-        return x;
+        return bits_to_float(__hip_atomic_load(&s_thr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       };
       auto refresh = [&](const int kstep) {
         if ((kstep & (BM_THR_EVERY - 1)) != 0) return;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -773,6 +774,34 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       HIP_TRY(vaq::launch_bm_plan(bp, st));
       HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
       HIP_TRY(vaq::launch_bm_select(bp, st));
+      if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what pass A handed over and what pass B appended
+        std::vector<unsigned> hq((size_t)3 * chunk), hthr((size_t)n);
+        std::vector<int> hcnt((size_t)ix->n_buckets);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(hq.data(), ix->w_bm_query.p, hq.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hcnt.data(), bp.cnt, hcnt.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long handed = 0, appended = 0, over = 0, maxc = 0, pairs = 0, groups = 0, work = 0;
+        for (int i = 0; i < n; i++) {
+          if (hq[i] != 0xffffffffu) handed++;
+          const unsigned c = hq[(size_t)chunk + i];
+          appended += c;
+          over += c > (unsigned)pl.bm_cap;
+          maxc = std::max<unsigned long long>(maxc, c);
+        }
+        std::vector<int> hb((size_t)ix->n_buckets + 1);
+        HIP_TRY(hipMemcpy(hb.data(), ix->d_bstart.p, hb.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < ix->n_buckets; b++) {
+          pairs += hcnt[b];
+          const unsigned long long g = (hcnt[b] + pl.bm_qb - 1) / pl.bm_qb;
+          groups += g;
+          work += g * (unsigned long long)(hb[b + 1] - hb[b]);
+        }
+        std::fprintf(stderr, "[VAQHIP_BM_DEBUG] queries %d handed over %llu; (query, bucket) pairs %llu, items %llu, row-steps x QB "
+                             "%.3e (= %.2f %% of rows per query slot); candidates appended %llu (max %llu per query), overflowed "
+                             "queries %llu; pass A units %d\n",
+                     n, handed, pairs, groups, (double)work * pl.bm_qb, 100.0 * (double)work * pl.bm_qb / ((double)n * (double)ix->N),
+                     appended, maxc, over, pl.defer_units);
+      }
     }
     if (defer || bm) {
       // second launch: what the expensive queries have left, DEFER_SLICES workgroups each (those
