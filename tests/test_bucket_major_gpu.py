@@ -73,6 +73,11 @@ def test_bucket_major_matches_oracle(vaqlib, oracle, seed, bits, N, nq, k, bb, k
         assert np.array_equal(l, base_l), what
         assert np.all(l[3] == -1)
     assert seen == 7
+    # the order inside the buckets (rows of a bucket sorted by the second code; the pass skips whole
+    # runs) is invisible: pass with the runs ignored, and an index built without that order
+    l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=0, bm_queries_per_group=0, bm_waves=0, bm_runs=0)
+    assert t["bucket_major"] == 1 and np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l)
+    v.set_option("bm_runs", 1)
     assert np.array_equal(base_d.view(np.uint32)[np.arange(nq) != 3], o_dis.view(np.uint32)[np.arange(nq) != 3])
     v.close()
 
@@ -125,3 +130,39 @@ def test_bucket_major_encoded_clustered(vaqlib, oracle):
     ad = oracle_all_dists(oracle, c, Xp)
     assert_topk_matches(l[:48], d[:48], o_lab, o_dis, ad, what="encoded, bucket-major")
     v.close()
+
+
+def test_bucket_major_after_appends(vaqlib, oracle):
+    """Rows appended in three pieces (vaqhip_index_add_codes_u16 merges them run by run, so the
+    order inside the buckets survives), and an index built without that order: same results."""
+    import vaq_amd
+    bits = [8] * 16
+    N, nq, k = 350_000, 64, 50
+    c = make_case(9301, 128, bits, N, nq, dup_frac=0.03)
+    Xp = oracle.project(c["X"], c["eig"])
+    o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=8)
+    ad = oracle_all_dists(oracle, c, Xp[:16])
+    res = {}
+    for sub_order in (1, 0):
+        v = vaq_amd.VaqHip()
+        v.mBitsAlloc = list(bits)
+        v.mCentroidsPerSubs = c["cents"]
+        v.mEigenVectors = c["eig"]
+        v._ensure_index()
+        v.set_option("sub_order", sub_order)
+        v.set_option("bucket_bits", 10)
+        v.mCodebook = c["codes"][:250_000]
+        v._ensure_codes()
+        v.add_codes(c["codes"][250_000:340_000])
+        v.add_codes(c["codes"][340_000:])
+        v.set_option("timing", 1)
+        for bm in (0, 2):
+            l, d, t = run(v, c["X"], k, bucket_major=bm, bm_units=1)
+            assert t["bucket_major"] == (1 if bm else 0)
+            res[(sub_order, bm)] = (l, d)
+        v.close()
+    base_l, base_d = res[(1, 0)]
+    assert_topk_matches(base_l[:16], base_d[:16], o_lab[:16], o_dis[:16], ad, what="appended")
+    assert np.array_equal(base_d.view(np.uint32), o_dis.view(np.uint32))
+    for key, (l, d) in res.items():
+        assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l), key

@@ -150,8 +150,11 @@ hipError_t launch_pack_codes(const uint16_t *codes_u16, int64_t row_begin, int64
 // Stable sort of rows by their subspace-0 code: d_perm[n] (sorted row -> original
 // row) and d_bucket_start[(1<<bits0)+1] (first sorted row of each code that
 // occurs, -1 otherwise; the caller back-fills).  Synchronises the stream.
+// fine > 0 (shift == 0): the rows of a bucket are also ordered by the next `fine` bits of the second
+// code, and d_sub_start[((1 << kbits) << fine) + 1] receives the first row of every run (-1: back-fill)
 hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift, int bits1,
-                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st);
+                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st, int fine = 0,
+                              int *d_sub_start = nullptr);
 // Appending: merge the (separately sorted and packed) new rows into the bucketed order, bucket by
 // bucket; *_start have K0 + 1 entries (back-filled); out_* are the new buffers
 hipError_t launch_merge_rows(const uint32_t *old_codes, const uint32_t *old_perm, const int *old_start,
@@ -218,6 +221,8 @@ struct BmParams {
   const uint32_t *perm;      // sorted row -> label, or nullptr = identity
   const int *bucket_start;   // [n_buckets + 1]
   int n_buckets, bucket_t;   // bucket = first code << bucket_t | top bucket_t bits of the second (bucket_shift == 0)
+  const int *sub_start;      // [(n_buckets << (8 - bucket_t)) + 1] first row of every (first code, second code) run
+                             //    when the rows of a bucket are ordered by the second code, else nullptr
   int M;
   const float *lut;          // [nq][lut_floats]
   int lut_floats;

@@ -333,23 +333,35 @@ __global__ void first_code_keys_kernel(const uint16_t *__restrict__ codes, int64
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   unsigned key = (codes[i * M] & mask) >> shift;
-  if (t > 0) key = (key << t) | ((codes[i * M + 1] & mask1) >> shift1);  // + top t bits of code 1
+  if (t > 0) key = (key << t) | ((codes[i * M + 1] & mask1) >> shift1);  // + top t bits of code 1 (t includes the fine bits)
   keys[i] = (uint16_t)key;
   idx[i] = (uint32_t)i;
 }
 
-// start[b] = first i with keys[i] == b, for the codes that occur (others stay -1)
-__global__ void bucket_bounds_kernel(const uint16_t *__restrict__ keys, int64_t n, int *__restrict__ start) {
+// start[b] = first i with keys[i] >> fine == b, for the keys that occur (others stay -1);
+// sub (optional): the same at the level of the whole key
+__global__ void bucket_bounds_kernel(const uint16_t *__restrict__ keys, int64_t n, int fine, int *__restrict__ start,
+                                     int *__restrict__ sub) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (i == 0 || keys[i] != keys[i - 1]) start[keys[i]] = (int)i;
+  const unsigned k = keys[i], kp = i > 0 ? keys[i - 1] : 0u;
+  if (i == 0 || (k >> fine) != (kp >> fine)) start[k >> fine] = (int)i;
+  if (sub && (i == 0 || k != kp)) sub[k] = (int)i;
 }
 
+// fine > 0 (needs shift == 0): the rows of a bucket are ordered by the NEXT `fine` bits of the second
+// code as well -- the sort key is bucket key << fine | those bits -- and d_sub_start[(K0 << fine) + 1]
+// receives the first row of every (bucket, fine value) run, like d_bucket_start.  Rows of a run share
+// their first two lookup-table terms whenever t + fine == bits1 (vaq_scan_bm.hip skips whole runs).
 hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bits0, int shift, int bits1,
-                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st) {
-  const int kbits = bits0 - shift + t;  // key: the first code's top bits0 - shift bits [+ t of code 1]
-  const int K0 = 1 << kbits;
+                              int t, uint32_t *d_perm, int *d_bucket_start, hipStream_t st, int fine,
+                              int *d_sub_start) {
+  const int kbits_b = bits0 - shift + t;  // bucket key: the first code's top bits0 - shift bits [+ t of code 1]
+  const int kbits = kbits_b + fine;
+  const int K0 = 1 << kbits_b;
+  if (fine < 0 || kbits > 16 || (fine > 0 && (shift != 0 || t + fine > bits1 || !d_sub_start))) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(d_bucket_start, 0xff, (size_t)(K0 + 1) * sizeof(int), st);
+  if (e == hipSuccess && fine > 0) e = hipMemsetAsync(d_sub_start, 0xff, ((size_t)(K0 << fine) + 1) * sizeof(int), st);
   if (e != hipSuccess || n == 0) return e;
   uint16_t *keys_in = nullptr, *keys_out = nullptr;
   uint32_t *idx_in = nullptr;
@@ -365,7 +377,7 @@ hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bit
   }
   const unsigned blocks = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(first_code_keys_kernel, dim3(blocks), dim3(256), 0, st, d_codes, n, M,
-                     (unsigned)((1 << bits0) - 1), shift, (unsigned)((1 << bits1) - 1), bits1 - t, t, keys_in,
+                     (unsigned)((1 << bits0) - 1), shift, (unsigned)((1 << bits1) - 1), bits1 - (t + fine), t + fine, keys_in,
                      idx_in);
   // stable LSD radix sort on the b0 key bits: equal codes keep ascending original rows
   e = rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
@@ -375,7 +387,8 @@ hipError_t sort_by_first_code(const uint16_t *d_codes, int64_t n, int M, int bit
     e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, d_perm, (size_t)n, 0u,
                                   (unsigned)kbits, st);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(bucket_bounds_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, d_bucket_start);
+    hipLaunchKernelGGL(bucket_bounds_kernel, dim3(blocks), dim3(256), 0, st, keys_out, n, fine, d_bucket_start,
+                       fine > 0 ? d_sub_start : (int *)nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);

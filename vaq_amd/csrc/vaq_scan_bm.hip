@@ -201,7 +201,13 @@ __host__ __device__ inline size_t bm_lds_bytes(int M, int qb, int nwaves) {
   return (size_t)M * 256 * qb * 4 + (size_t)nwaves * BM_QCAP * 4 * (3 + qcw);
 }
 
-template <int M, int QB>
+constexpr int BM_MAX_RUNS = 256;  // second codes of a bucket (bucket_t == 0: all 256)
+
+// SUB: the rows of a bucket are ordered by the second code (BmParams::sub_start): a RUN of rows shares
+// its first two table terms, so l0 + l1 is one value per (run, query) -- the first early-abandon test
+// of VAQ::searchEarlyAbandon (VAQ.cpp:1708) for a whole run at once.  Runs out of every query's reach
+// are never read; the others start at the third term.
+template <int M, int QB, bool SUB>
 __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   typedef BfBytesItem<M, (M < 16 ? 16 : M)> Item;
   typedef typename BmVec<QB>::T VT;
@@ -214,6 +220,9 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   __shared__ int s_ticket;
   __shared__ unsigned s_thr[QB];
   __shared__ int s_q[QB];
+  // runs of the item's bucket (SUB): rows, prefix of the wave steps of the runs in reach, l0 + l1 per query
+  __shared__ int s_run_s[SUB ? BM_MAX_RUNS : 1], s_run_e[SUB ? BM_MAX_RUNS : 1], s_cum[SUB ? BM_MAX_RUNS + 1 : 1];
+  __shared__ float s_p01[SUB ? BM_MAX_RUNS * QB : 1];
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   float *lut = reinterpret_cast<float *>(smem);  // entry (t * 256 + c) of query i at (t * 256 + c) * QB + i
@@ -258,6 +267,57 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
 #pragma unroll
       for (int i = 0; i < QB; i++) qi[i] = __builtin_amdgcn_readfirstlane(p.qlist[qbase + (i < nact ? i : 0)]);
       const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
+      if (tid < QB) {
+        // (per-lane picks among the group's queries and thresholds go through LDS: a register array
+        //  indexed by a lane value ends up in scratch memory)
+        const int myq = p.qlist[qbase + (tid < nact ? tid : 0)];
+        s_q[tid] = myq;
+        s_thr[tid] = tid < nact ? __hip_atomic_load(&p.g_thr[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : 0xbf800000u;  // -1: nothing passes (a slot past the end of the bucket's list)
+      }
+      __syncthreads();
+      int nsteps;  // wave steps of the item
+      if (SUB) {
+        // ---- the bucket's runs: l0 + l1 per query, and which of them some query of the group can
+        //      still reach (thresholds have moved since the plan was made) ----
+        const int R = 256 >> bt;
+        const int f0 = b << (8 - bt), c1base = (b & ((1 << bt) - 1)) << (8 - bt);
+        for (int j = tid; j < R; j += nthreads) {
+          const int rs = p.sub_start[f0 + j], re = p.sub_start[f0 + j + 1];
+          bool any = false;
+#pragma unroll
+          for (int i = 0; i < QB; i++) {
+            const float *__restrict__ gl = p.lut + (size_t)qi[i] * p.lut_floats;
+            const float v = gl[b >> bt] + gl[256 + c1base + j];  // dism = l0; dism += l1
+            s_p01[j * QB + i] = v;
+            any = any || v <= bits_to_float(s_thr[i]);
+          }
+          s_run_s[j] = rs;
+          s_run_e[j] = re;
+          s_cum[j + 1] = (any && re > rs) ? (re - (rs & ~(WSTEP - 1)) + WSTEP - 1) / WSTEP : 0;
+        }
+        if (tid == 0) s_cum[0] = 0;
+        __syncthreads();
+        if (wave == 0) {  // inclusive prefix, 64 at a time
+          int carry = 0;
+          for (int base = 0; base < R; base += 64) {
+            const int i = base + lane;
+            int inc = i < R ? s_cum[i + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int x = __shfl_up(inc, o);
+              if (lane >= o) inc += x;
+            }
+            if (i < R) s_cum[i + 1] = carry + inc;
+            carry += __builtin_amdgcn_readlane(inc, 63);
+          }
+        }
+        __syncthreads();
+        nsteps = s_cum[R];
+        if (nsteps == 0) continue;  // (every thread alike) nothing of this bucket is in the group's reach any more
+      } else {
+        nsteps = (be - (bs & ~(WSTEP - 1)) + WSTEP - 1) / WSTEP;
+      }
       // ---- the group's lookup tables, interleaved per entry ----
       {
         const float4 *g4[QB];
@@ -281,14 +341,6 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
           dst[2] = o2;
           dst[3] = o3;
         }
-      }
-      if (tid < QB) {
-        // (per-lane picks among the group's queries and thresholds go through LDS: a register array
-        //  indexed by a lane value ends up in scratch memory)
-        const int myq = p.qlist[qbase + (tid < nact ? tid : 0)];
-        s_q[tid] = myq;
-        s_thr[tid] = tid < nact ? __hip_atomic_load(&p.g_thr[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : 0xbf800000u;  // -1: nothing passes (a slot past the end of the bucket's list)
       }
       __syncthreads();
 
@@ -403,35 +455,55 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         append(acc, row, i, alive);
       };
 
-      auto step = [&](const Item &cur, const int kstep) {
-        const int base = (bs & ~(WSTEP - 1)) + (wave + kstep * nwaves) * WSTEP;
+      // rows [rs, re) of the step's item at `base`; p01 (SUB): l0 + l1 of the run, per query
+      auto step = [&](const Item &cur, const int kstep, const int base, const int rs, const int re, const float *p01) {
         refresh(kstep);
-        const bool interior = base >= bs && base + WSTEP <= be;  // wave-uniform
+        if (SUB) {  // the run may have dropped out of reach since the item began
+          bool dead = true;
+#pragma unroll
+          for (int i = 0; i < QB; i++) dead = dead && !(p01[i] <= thr[i]);
+          if (dead) return;
+        }
+        const bool interior = base >= rs && base + WSTEP <= re;  // wave-uniform
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
           const int row = base + lane * ROWS + r;
           const uint32_t c0 = cur.word(r, 0);
-          const bool in_range = interior || (row >= bs && row < be);
-          // A: dism = l0; dism += l1
-          const VT v1 = *reinterpret_cast<const VT *>(&lut[(size_t)(256 + ((c0 >> 8) & 0xffu)) * QB]);
+          const bool in_range = interior || (row >= rs && row < re);
           float part[QB];
           bool alive[QB];
           bool any = false;
-#pragma unroll
-          for (int i = 0; i < QB; i++) {
-            part[i] = l0[i] + v1[i];
-            alive[i] = in_range && part[i] <= thr[i];
-            any = any || alive[i];
-          }
-          if (__ballot(any) == 0ull) continue;
-          if (any) {  // A2: dism += l2; dism += l3 -> the first group's sum
+          if (SUB) {
+            // dism (= l0 + l1, the run's) += l2; dism += l3 -> the first group's sum
             const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
             const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
 #pragma unroll
             for (int i = 0; i < QB; i++) {
-              part[i] = part[i] + v2[i];
+              part[i] = p01[i] + v2[i];
               part[i] = part[i] + v3[i];
-              alive[i] = alive[i] && part[i] <= thr[i];
+              alive[i] = in_range && part[i] <= thr[i];
+              any = any || alive[i];
+            }
+            if (__ballot(any) == 0ull) continue;
+          } else {
+            // A: dism = l0; dism += l1
+            const VT v1 = *reinterpret_cast<const VT *>(&lut[(size_t)(256 + ((c0 >> 8) & 0xffu)) * QB]);
+#pragma unroll
+            for (int i = 0; i < QB; i++) {
+              part[i] = l0[i] + v1[i];
+              alive[i] = in_range && part[i] <= thr[i];
+              any = any || alive[i];
+            }
+            if (__ballot(any) == 0ull) continue;
+            if (any) {  // A2: dism += l2; dism += l3 -> the first group's sum
+              const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
+              const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
+#pragma unroll
+              for (int i = 0; i < QB; i++) {
+                part[i] = part[i] + v2[i];
+                part[i] = part[i] + v3[i];
+                alive[i] = alive[i] && part[i] <= thr[i];
+              }
             }
           }
 #pragma unroll
@@ -453,30 +525,53 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         }
       };
 
-      // ---- the bucket's rows: wave w takes steps w, w + nwaves, ... (the workgroup streams the
-      //      bucket front to back, as every other group of this bucket does at the same time) ----
-      const int base00 = bs & ~(WSTEP - 1);
-      const int nsteps = (be - base00 + WSTEP - 1) / WSTEP;
+      // ---- the item's wave steps: wave w takes steps w, w + nwaves, ... (the workgroup streams the
+      //      rows front to back, as every other group of this bucket does at the same time) ----
       const int nmine = wave < nsteps ? (nsteps - wave + nwaves - 1) / nwaves : 0;
       if (nmine > 0) {
-        auto item_of = [&](const int kk) -> int64_t {
+        const int base00 = bs & ~(WSTEP - 1);
+        // step number -> first row of its item (SUB: through the prefix of the live runs' steps; the
+        // cursor only moves forward) [+ the run's rows and l0 + l1]
+        auto step_base = [&](const int kk, int &cursor) -> int {
           const int kc = kk < nmine - 1 ? kk : nmine - 1;
-          return (int64_t)((base00 + (wave + kc * nwaves) * WSTEP) / ROWS) + lane;
+          const int sidx = wave + kc * nwaves;
+          if (!SUB) return base00 + sidx * WSTEP;
+          while (__builtin_amdgcn_readfirstlane(s_cum[cursor + 1]) <= sidx) cursor++;
+          return (__builtin_amdgcn_readfirstlane(s_run_s[cursor]) & ~(WSTEP - 1)) +
+                 (sidx - __builtin_amdgcn_readfirstlane(s_cum[cursor])) * WSTEP;
+        };
+        int cur_l = 0, cur_p = 0, run_p = -1;  // cursors of the loads (ahead) and of the steps; run whose data is cached
+        int rs = bs, re = be;
+        float p01[QB];
+#pragma unroll
+        for (int i = 0; i < QB; i++) p01[i] = 0.0f;
+        auto do_step = [&](const Item &it, const int kk) {
+          const int base = step_base(kk, cur_p);
+          if (SUB && cur_p != run_p) {
+            run_p = cur_p;
+            rs = __builtin_amdgcn_readfirstlane(s_run_s[cur_p]);
+            re = __builtin_amdgcn_readfirstlane(s_run_e[cur_p]);
+#pragma unroll
+            for (int i = 0; i < QB; i++)
+              p01[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(s_p01[cur_p * QB + i])));
+          }
+          step(it, kk, base, rs, re, p01);
         };
         Item ring[BM_RING];
 #pragma unroll
-        for (int u = 0; u < BM_RING; u++) ring[u].load(codes, item_of(u));
+        for (int u = 0; u < BM_RING; u++) ring[u].load(codes, (int64_t)(step_base(u, cur_l) / ROWS) + lane);
         int kk = 0;
         for (; kk + BM_RING <= nmine; kk += BM_RING) {
 #pragma unroll
           for (int u = 0; u < BM_RING; u++) {
-            step(ring[u], kk + u);
-            ring[u].load(codes, item_of(kk + u + BM_RING));  // (past the end: the last item again, a cache hit)
+            do_step(ring[u], kk + u);
+            // (past the end: the last item again, a cache hit)
+            ring[u].load(codes, (int64_t)(step_base(kk + u + BM_RING, cur_l) / ROWS) + lane);
           }
         }
 #pragma unroll
         for (int u = 0; u < BM_RING; u++)
-          if (kk + u < nmine) step(ring[u], kk + u);
+          if (kk + u < nmine) do_step(ring[u], kk + u);
       }
       while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
     }
@@ -592,17 +687,20 @@ hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st) {
   if (p.nq <= 0) return hipSuccess;
   if (p.nwaves < 1 || p.nwaves > 16) return hipErrorInvalidValue;
   const size_t lds = bm_lds_bytes(p.M, p.qb, p.nwaves);
-  if (lds + 1024 > 160 * 1024) return hipErrorInvalidValue;
+  if (lds + 8192 > 160 * 1024) return hipErrorInvalidValue;  // (+ the static tables)
   // persistent workgroups: as many as are resident at once, a multiple of the XCD count
-  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  int per_cu = (int)((160 * 1024) / (lds + 8192));
   const int by_waves = 32 / p.nwaves;
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   per_cu = per_cu < 1 ? 1 : per_cu;
   const int grid = ((n_cu * per_cu + BM_XCDS - 1) / BM_XCDS) * BM_XCDS;
-#define VAQ_BM_CASE(MM)                                                                         \
-  case MM:                                                                                      \
-    return p.qb == 4 ? launch_bm_kernel(scan_bm_kernel<MM, 4>, p, lds, grid, st)                \
-                     : launch_bm_kernel(scan_bm_kernel<MM, 2>, p, lds, grid, st);
+#define VAQ_BM_CASE(MM)                                                                               \
+  case MM:                                                                                            \
+    if (p.sub_start)                                                                                  \
+      return p.qb == 4 ? launch_bm_kernel(scan_bm_kernel<MM, 4, true>, p, lds, grid, st)              \
+                       : launch_bm_kernel(scan_bm_kernel<MM, 2, true>, p, lds, grid, st);             \
+    return p.qb == 4 ? launch_bm_kernel(scan_bm_kernel<MM, 4, false>, p, lds, grid, st)               \
+                     : launch_bm_kernel(scan_bm_kernel<MM, 2, false>, p, lds, grid, st);
   switch (p.M) {
     VAQ_BM_CASE(8)
     VAQ_BM_CASE(16)

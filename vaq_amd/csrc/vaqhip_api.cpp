@@ -103,6 +103,11 @@ struct vaqhip_index {
   std::vector<int> bits;
   std::vector<vaq::SubDesc> sub;
   DevBuf d_cent, d_cent_t, d_eig, d_sub, d_first_sub, d_codes, d_perm, d_bstart;
+  // byte codes bucketed by the whole first code: rows of a bucket are ordered by the rest of the
+  // second code too, d_sub holds the first row of every (first code, second code) run
+  // (sub_fine = bits of the second code below the bucket key; 0 = no such order, e.g. after an append)
+  DevBuf d_substart;
+  int sub_fine = 0;
   bool has_eig = false;
   int seq = 0;  // 1: BitVecEngine::queryLUT's sequential row sum
   int bucket_shift = 0, bucket_t = 0, n_buckets = 1;  // bucketed row order (set with the codes)
@@ -129,7 +134,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0, opt_sub_order = 1, opt_bm_sub = 1;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -359,7 +364,7 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
         pl->bm_qb = ix->opt_bm_qb > 0 ? ix->opt_bm_qb : BM_QB;
         pl->bm_nwaves = ix->opt_bm_nwaves > 0 ? ix->opt_bm_nwaves : BM_NWAVES;
         pl->bm_cap = ix->opt_bm_cap > 0 ? ix->opt_bm_cap : BM_CAND_CAP;
-        while (vaq::scan_bm_lds_bytes(ix->M, pl->bm_qb, pl->bm_nwaves) + 2048 > LDS_LIMIT && pl->bm_nwaves > 4) pl->bm_nwaves >>= 1;
+        while (vaq::scan_bm_lds_bytes(ix->M, pl->bm_qb, pl->bm_nwaves) + 8192 > LDS_LIMIT && pl->bm_nwaves > 4) pl->bm_nwaves >>= 1;
         // pass A: about one average bucket per query (a work unit = 64 wave steps)
         const int64_t unit_rows = 64 * (int64_t)(vaq::scan_wg_step_rows(ix->layout, ix->M) / vaq::SCAN_MAX_WAVES);
         const int64_t avg = N / ix->n_buckets + 1;
@@ -727,6 +732,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       bp.bucket_start = sp.bucket_start;
       bp.n_buckets = sp.n_buckets;
       bp.bucket_t = sp.bucket_t;
+      bp.sub_start = (ix->sub_fine > 0 && ix->sub_fine + ix->bucket_t == 8 && ix->opt_bm_sub) ? ix->d_substart.as<int>() : nullptr;
       bp.M = ix->M;
       bp.lut = sp.lut;
       bp.lut_floats = sp.lut_floats;
@@ -1032,7 +1038,7 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   const int64_t words = vaq::packed_words(padded, ix->M, ix->layout, ix->W);
   HIP_TRY(ix->d_codes.ensure((size_t)words * sizeof(uint32_t)));
   const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
-  int shift = 0, bt = 0, K0 = 1;
+  int shift = 0, bt = 0, K0 = 1, fine = 0;
   if (ix->ti_T > 0) {
     K0 = ix->ti_T;
   } else {
@@ -1073,9 +1079,22 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
       HIP_TRY(vaq::ti_group_rows(d_u16, N, ix->M, ix->L, ix->ti_seg, dsub, ix->d_cent.as<float>(),
                                  ix->d_ti_clusters.as<float>(), ix->ti_T, ix->d_perm.as<uint32_t>(),
                                  ix->d_bstart.as<int>(), ix->d_ti_xcc.as<float>(), st));
-    else
+    else {
+      // (byte codes keyed by the whole first code: order each bucket by the rest of the second code)
+      fine = (ix->layout == vaq::LAYOUT_BYTES && shift == 0 && ix->M > 1 && ix->opt_sub_order) ? ix->bits[1] - bt : 0;
+      if (fine > 0) HIP_TRY(ix->d_substart.ensure((((size_t)K0 << fine) + 1) * sizeof(int)));
       HIP_TRY(vaq::sort_by_first_code(d_u16, N, ix->M, ix->bits[0], shift, ix->M > 1 ? ix->bits[1] : 0, bt,
-                                      ix->d_perm.as<uint32_t>(), ix->d_bstart.as<int>(), st));
+                                      ix->d_perm.as<uint32_t>(), ix->d_bstart.as<int>(), st, fine,
+                                      fine > 0 ? ix->d_substart.as<int>() : nullptr));
+      if (fine > 0) {
+        std::vector<int> ss(((size_t)K0 << fine) + 1);
+        HIP_TRY(hipMemcpy(ss.data(), ix->d_substart.p, ss.size() * sizeof(int), hipMemcpyDeviceToHost));
+        ss[ss.size() - 1] = (int)N;
+        for (int64_t f = (int64_t)ss.size() - 2; f >= 0; f--)
+          if (ss[f] < 0) ss[f] = ss[f + 1];  // runs that do not occur: empty
+        HIP_TRY(hipMemcpy(ix->d_substart.p, ss.data(), ss.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
+    }
     HIP_TRY(hipMemcpy(bstart.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
     bstart[K0] = (int)N;
     for (int b = K0 - 1; b >= 0; b--)
@@ -1090,6 +1109,7 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   ix->bucket_shift = shift;
   ix->bucket_t = bt;
   ix->n_buckets = K0;
+  ix->sub_fine = N > 0 ? fine : 0;
   return VAQHIP_OK;
 }
 
@@ -1128,22 +1148,29 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
 // O(n_new) plus the new packed buffer.
 static int append_rows_bucketed(vaqhip_index *ix, const uint16_t *d_new, int64_t n_new, hipStream_t st) {
   const int64_t n_old = ix->N, N = n_old + n_new;
-  const int K0 = ix->n_buckets;
+  // (rows ordered inside the buckets too: merge run by run, so that the order survives -- the runs
+  //  are the buckets of a finer key, ix->d_substart their starts)
+  const int fine = ix->sub_fine;
+  const int KB = ix->n_buckets;
+  const int K0 = KB << fine;
   const int step = vaq::scan_wg_step_rows(ix->layout, ix->M);
   const vaq::SubDesc *dsub = ix->d_sub.as<vaq::SubDesc>();
   // the new rows in bucketed order among themselves
-  DevBuf new_perm, new_start, new_codes, out_codes, out_perm;
+  DevBuf new_perm, new_start, new_bstart, new_codes, out_codes, out_perm;
   HIP_TRY(new_perm.ensure((size_t)n_new * sizeof(uint32_t)));
   HIP_TRY(new_start.ensure((size_t)(K0 + 1) * sizeof(int)));
+  HIP_TRY(new_bstart.ensure((size_t)(KB + 1) * sizeof(int)));
   HIP_TRY(vaq::sort_by_first_code(d_new, n_new, ix->M, ix->bits[0], ix->bucket_shift, ix->M > 1 ? ix->bits[1] : 0,
-                                  ix->bucket_t, new_perm.as<uint32_t>(), new_start.as<int>(), st));
+                                  ix->bucket_t, new_perm.as<uint32_t>(), fine > 0 ? new_bstart.as<int>() : new_start.as<int>(), st,
+                                  fine, fine > 0 ? new_start.as<int>() : nullptr));
   std::vector<int> ns((size_t)K0 + 1), os((size_t)K0 + 1), ts((size_t)K0 + 1);
   HIP_TRY(hipMemcpy(ns.data(), new_start.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
   ns[K0] = (int)n_new;
   for (int b = K0 - 1; b >= 0; b--)
     if (ns[b] < 0) ns[b] = ns[b + 1];
   HIP_TRY(hipMemcpy(new_start.p, ns.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(os.data(), ix->d_bstart.p, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  const int *d_old_start = fine > 0 ? ix->d_substart.as<int>() : ix->d_bstart.as<int>();
+  HIP_TRY(hipMemcpy(os.data(), d_old_start, (size_t)(K0 + 1) * sizeof(int), hipMemcpyDeviceToHost));
   const int64_t new_padded = std::max<int64_t>(step, ((n_new + step - 1) / step) * step);
   HIP_TRY(new_codes.ensure((size_t)vaq::packed_words(new_padded, ix->M, ix->layout, ix->W) * sizeof(uint32_t)));
   HIP_TRY(vaq::launch_pack_codes(d_new, 0, n_new, new_padded, ix->M, ix->layout, ix->W, dsub, new_perm.as<uint32_t>(),
@@ -1154,7 +1181,7 @@ static int append_rows_bucketed(vaqhip_index *ix, const uint16_t *d_new, int64_t
   HIP_TRY(out_codes.ensure((size_t)words * sizeof(uint32_t)));
   HIP_TRY(out_perm.ensure((size_t)N * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(out_codes.p, 0, (size_t)words * sizeof(uint32_t), st));  // (the padding rows must be zero)
-  HIP_TRY(vaq::launch_merge_rows(ix->d_codes.as<uint32_t>(), ix->d_perm.as<uint32_t>(), ix->d_bstart.as<int>(),
+  HIP_TRY(vaq::launch_merge_rows(ix->d_codes.as<uint32_t>(), ix->d_perm.as<uint32_t>(), d_old_start,
                                  new_codes.as<uint32_t>(), new_perm.as<uint32_t>(), new_start.as<int>(), K0, n_old, N,
                                  ix->M, ix->layout, ix->W, out_codes.as<uint32_t>(), out_perm.as<uint32_t>(), st));
   for (int b = 0; b <= K0; b++) ts[b] = os[b] + ns[b];
@@ -1163,7 +1190,14 @@ static int append_rows_bucketed(vaqhip_index *ix, const uint16_t *d_new, int64_t
   std::swap(ix->d_codes.cap, out_codes.cap);
   std::swap(ix->d_perm.p, out_perm.p);
   std::swap(ix->d_perm.cap, out_perm.cap);
-  HIP_TRY(hipMemcpy(ix->d_bstart.p, ts.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (fine > 0) {
+    HIP_TRY(hipMemcpy(ix->d_substart.p, ts.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> tb((size_t)KB + 1);
+    for (int b = 0; b <= KB; b++) tb[b] = ts[(size_t)b << fine];
+    HIP_TRY(hipMemcpy(ix->d_bstart.p, tb.data(), (size_t)(KB + 1) * sizeof(int), hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMemcpy(ix->d_bstart.p, ts.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
+  }
   ix->N = N;
   return VAQHIP_OK;
 }
@@ -1622,6 +1656,10 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "defer_units") {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
+  } else if (k == "bm_runs") {
+    ix->opt_bm_sub = value != 0;  // 0: the bucket-major pass ignores the order inside the buckets (every row of a bucket read)
+  } else if (k == "sub_order") {
+    ix->opt_sub_order = value != 0;  // takes effect when the codes are (re)set
   } else if (k == "bucket_major") {
     if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "bucket_major must be 0 (off), 1 (automatic) or 2 (whenever a kernel exists)");
     ix->opt_bm = (int)value;
