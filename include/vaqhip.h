@@ -341,6 +341,15 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       overflows it is finished by the best-first form
  *   "bm_units"          work units (64 wave steps) of the first pass per query; 0 = about one
  *                       average bucket
+ *   "bm_boot"           1 (default): no best-first pass at all -- every query gets a threshold from a
+ *                       sample of its nearest rows, and its nearest bucket is the first bucket-major
+ *                       round; 0: the capped best-first pass ("bm_units") comes first
+ *   "bm_round"          buckets per query of the middle round (default 6, 0 = no middle round): after
+ *                       it the thresholds are near their final values, and the last round -- every
+ *                       bucket still in reach -- meets far fewer rows
+ *   "bm_runs"           1 (default): runs of rows sharing their first two codes are skipped when out of
+ *                       every query's reach ("sub_order": the rows of a bucket are kept ordered by the
+ *                       second code; set before the codes)
  *   "bm_queries_per_group", "bm_waves"   launch shape of the second pass (0 = default 4 / 16)    */
 int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value);
 

@@ -64,19 +64,25 @@ def test_bucket_major_matches_oracle(vaqlib, oracle, seed, bits, N, nq, k, bb, k
     assert t0["bucket_major"] == 0
     assert_topk_matches(base_l[:24], base_d[:24], o_lab[:24], o_dis[:24], ad, what="one workgroup per query")
     seen = 0
-    for units, cap, qb, nw in [(0, 0, 0, 0), (1, 0, 4, 16), (1, 0, 2, 8), (4, 0, 4, 4), (1, 8, 4, 16), (2, 64, 2, 16),
-                               (100000, 0, 0, 0)]:
-        l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=units, bm_candidates=cap, bm_queries_per_group=qb, bm_waves=nw)
+    # (work units of a best-first first pass | 0 = sampled thresholds instead, candidate slots, queries per
+    #  group, waves, buckets of the middle round)
+    shapes = [(0, 0, 0, 0, 6), (0, 0, 4, 16, 0), (0, 8, 2, 8, 1), (0, 64, 4, 4, 3), (0, 1, 0, 0, 2),
+              (1, 0, 4, 16, 0), (1, 0, 2, 8, 2), (4, 0, 4, 4, 6), (1, 8, 4, 16, 0), (2, 64, 2, 16, 1), (100000, 0, 0, 0, 0)]
+    for units, cap, qb, nw, rnd in shapes:
+        l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=0 if units else 1, bm_units=units, bm_candidates=cap,
+                      bm_queries_per_group=qb, bm_waves=nw, bm_round=rnd)
         seen += t["bucket_major"]
-        what = f"units={units} cap={cap} qb={qb} nw={nw}"
+        what = f"units={units} cap={cap} qb={qb} nw={nw} round={rnd}"
         assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)), what
         assert np.array_equal(l, base_l), what
         assert np.all(l[3] == -1)
-    assert seen == 7
+    assert seen == len(shapes)
     # the order inside the buckets (rows of a bucket sorted by the second code; the pass skips whole
     # runs) is invisible: pass with the runs ignored, and an index built without that order
-    l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=0, bm_queries_per_group=0, bm_waves=0, bm_runs=0)
-    assert t["bucket_major"] == 1 and np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l)
+    for boot in (0, 1):
+        l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=boot, bm_units=1, bm_candidates=0, bm_queries_per_group=0,
+                      bm_waves=0, bm_runs=0, bm_round=6)
+        assert t["bucket_major"] == 1 and np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l)
     v.set_option("bm_runs", 1)
     assert np.array_equal(base_d.view(np.uint32)[np.arange(nq) != 3], o_dis.view(np.uint32)[np.arange(nq) != 3])
     v.close()
@@ -93,10 +99,10 @@ def test_bucket_major_overflow_and_small_k(vaqlib, oracle):
         v = make_index(c)
         v.set_option("timing", 1)
         base_l, base_d, _ = run(v, c["X"], k, bucket_major=0)
-        for cap in (1, 0):
-            l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=cap)
+        for cap, boot in ((1, 0), (0, 0), (1, 1), (0, 1)):
+            l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=cap, bm_boot=boot)
             assert t["bucket_major"] == 1
-            assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l), (k, cap)
+            assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l), (k, cap, boot)
         assert np.array_equal(base_d.view(np.uint32), o_dis.view(np.uint32))
         v.close()
 
@@ -121,10 +127,11 @@ def test_bucket_major_encoded_clustered(vaqlib, oracle):
     v = make_index(c, 10)
     v.set_option("timing", 1)
     base_l, base_d, t0 = run(v, c["X"], k, bucket_major=0)
-    l, d, t = run(v, c["X"], k, bucket_major=2)
-    assert t["bucket_major"] == 1 and t0["bucket_major"] == 0
-    assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32))
-    assert np.array_equal(l, base_l)
+    for boot in (1, 0):
+        l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=boot)
+        assert t["bucket_major"] == 1 and t0["bucket_major"] == 0
+        assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32))
+        assert np.array_equal(l, base_l)
     Xp = oracle.project(c["X"][:48], c["eig"])
     o_lab, o_dis = oracle.search(Xp, c["cents"], c["codes"], k, max_bits=8, projected=True, nthreads=16)
     ad = oracle_all_dists(oracle, c, Xp)
@@ -156,12 +163,12 @@ def test_bucket_major_after_appends(vaqlib, oracle):
         v.add_codes(c["codes"][250_000:340_000])
         v.add_codes(c["codes"][340_000:])
         v.set_option("timing", 1)
-        for bm in (0, 2):
-            l, d, t = run(v, c["X"], k, bucket_major=bm, bm_units=1)
+        for bm, boot in ((0, 0), (2, 0), (2, 1)):
+            l, d, t = run(v, c["X"], k, bucket_major=bm, bm_units=1, bm_boot=boot)
             assert t["bucket_major"] == (1 if bm else 0)
-            res[(sub_order, bm)] = (l, d)
+            res[(sub_order, bm, boot)] = (l, d)
         v.close()
-    base_l, base_d = res[(1, 0)]
+    base_l, base_d = res[(1, 0, 0)]
     assert_topk_matches(base_l[:16], base_d[:16], o_lab[:16], o_dis[:16], ad, what="appended")
     assert np.array_equal(base_d.view(np.uint32), o_dis.view(np.uint32))
     for key, (l, d) in res.items():

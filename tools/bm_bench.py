@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--random-codes", action="store_true")
     ap.add_argument("--skip-base", action="store_true", help="do not time the one-workgroup-per-query form")
     ap.add_argument("--units", default="", help="comma-separated bm_units values to time (instead of the default shape)")
+    ap.add_argument("--rounds", default="", help="comma-separated bm_boot:bm_round pairs to time")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -70,7 +71,9 @@ def main():
         ref = (l0, d0)
     shapes = [dict(bucket_major=2)]
     if a.units:
-        shapes = [dict(bucket_major=2, bm_units=int(u)) for u in a.units.split(",")]
+        shapes = [dict(bucket_major=2, bm_boot=0, bm_units=int(u)) for u in a.units.split(",")]
+    if a.rounds:  # "boot:round" pairs, e.g. 1:6,1:0,0:6
+        shapes = [dict(bucket_major=2, bm_boot=int(x.split(":")[0]), bm_round=int(x.split(":")[1])) for x in a.rounds.split(",")]
     if a.sweep:
         shapes += [dict(bucket_major=2, bm_units=u) for u in (8, 32, 128, 512)]
         shapes += [dict(bucket_major=2, bm_units=0, bm_queries_per_group=2), dict(bucket_major=2, bm_queries_per_group=4, bm_waves=8)]

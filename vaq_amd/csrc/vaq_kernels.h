@@ -42,7 +42,7 @@ struct DeferRec {
   int q;              // query (index within the call)
   unsigned done_key;  // buckets with keys <= this were scanned by the first launch
   unsigned thr;       // its threshold when it stopped (float bits): an upper bound of the final k-th distance
-  int pad;
+  int pad;            // != 0: no bucket is finished yet (done_key is not a key)
 };
 
 struct ScanParams {
@@ -229,7 +229,10 @@ struct BmParams {
   int nq, k, qb;
   int nwaves;
   unsigned *g_thr;           // [nq] float bits: thresholds (rows AT them stay admissible)
-  const unsigned *done_key;  // [nq]
+  unsigned *done_key;        // [nq] buckets with keys <= this are finished; 0xffffffff: the query is complete
+  unsigned *done_next;       // [nq] what done_key becomes when the round's select succeeds
+  int first;                 // 1: no bucket is finished yet (done_key is ignored: the round after launch_bm_boot)
+  int limit;                 // buckets a query takes in this round, nearest first (<= 0: all in reach)
   // plan (device, written by launch_bm_plan)
   unsigned *mask;            // [nq][n_buckets / 32] buckets still in reach
   int *cnt;                  // [n_buckets] queries per bucket
@@ -261,6 +264,10 @@ size_t scan_bm_lds_bytes(int M, int qb, int nwaves);
 size_t bm_plan_small_words(int n_buckets);
 // mark + count, order + prefix, fill (three launches)
 hipError_t launch_bm_plan(const BmParams &p, hipStream_t st);
+// instead of a best-first first pass: per query a threshold from a sample of its nearest rows (the k-th
+// smallest complete sum of up to 4096 rows starting at the nearest run of the nearest bucket), an empty
+// result list, nothing finished (the first round is then planned with BmParams::first = 1)
+hipError_t launch_bm_boot(const BmParams &p, int64_t n_rows, hipStream_t st);
 hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st);
 hipError_t launch_bm_select(const BmParams &p, hipStream_t st);
 

@@ -438,6 +438,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   const bool defer2 = p.defer_mode != 0;
   int slice, qi, ent = 0;
   unsigned rec_done = 0u, rec_thr = 0u;
+  bool rec_none = false;  // (DeferRec::pad != 0: no bucket of the query is finished yet, done_key means nothing)
   if (defer2) {
     const unsigned asked = *p.defer_count;
     const int cnt = asked < (unsigned)p.defer_cap ? (int)asked : p.defer_cap;
@@ -448,6 +449,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     qi = __builtin_amdgcn_readfirstlane(rec.q);
     rec_done = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.done_key);
     rec_thr = (unsigned)__builtin_amdgcn_readfirstlane((int)rec.thr);
+    rec_none = __builtin_amdgcn_readfirstlane(rec.pad) != 0;
   } else if (p.qorder) {
     // one workgroup per query, expensive queries first (launch_cost_order): block b, dispatched b-th
     // and dealt to XCD b % 8, serves the b-th query of the ranking
@@ -865,7 +867,7 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   // ---- rounds: the eligible buckets (bound not above the threshold, not done yet), nearest first,
   //      at most BF_ROUND_BUCKETS per round; thresholds fall while a round runs, so a second round
   //      is rarely anything but the check that nothing is left ----
-  bool first_round = !defer2;
+  bool first_round = !defer2 || rec_none;
   bool defer_tried = false;
   bool bm_handed = false;  // (bucket-major second pass follows: publish the exact k-th distance)
   unsigned done_key = rec_done;  // buckets with keys <= done_key are finished (after the first round)

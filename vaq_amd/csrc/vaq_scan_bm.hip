@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   __shared__ unsigned gmin[1 << GMIN_MAX_BITS];
   __shared__ unsigned smask[BF_MAX_BUCKETS / 32];
   __shared__ unsigned shist[BM_HIST_BINS];
+  __shared__ unsigned s_cnt[2];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int K0 = p.n_buckets, bt = p.bucket_t;
   const int nwords = K0 / 32;
@@ -67,10 +68,12 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   if (tid == 0) p.cand_cnt[q] = 0u;
   if (tid < BM_HIST_BINS) shist[tid] = 0u;
   if (tid < nwords) smask[tid] = 0u;
+  if (tid < 2) s_cnt[tid] = 0u;
   const unsigned thr_bits = p.g_thr[q];
   const float H = bits_to_float(thr_bits);
   const float scale = (done != 0xffffffffu && H > 0.0f && H < FLT_MAX) ? (float)BM_HIST_BINS / H : 0.0f;
-  if (done != 0xffffffffu) {  // (wave-uniform: pass A left buckets in reach)
+  unsigned next = 0xffffffffu;
+  if (done != 0xffffffffu) {  // (workgroup-uniform: the query still has buckets in reach)
     const float *__restrict__ l = p.lut + (size_t)q * p.lut_floats;
     if (bt > 0) {
       if (tid < (1 << bt)) gmin[tid] = 0x7f800000u;
@@ -89,26 +92,67 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
       }
     }
     __syncthreads();
-    const unsigned idx_mask = (unsigned)K0 - 1u;  // (K0 is a power of two >= 16)
+    const unsigned idx_mask = (unsigned)K0 - 1u;  // (K0 is a power of two >= 32)
     const unsigned empty_key = ~idx_mask;
-    for (int b = tid; b < K0; b += blockDim.x) {
-      const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
-      if (be <= bs) continue;
-      float m;
-      if (bt > 0) {
-        m = l[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
-      } else {
-        const float x = l[b];
-        m = x < INFINITY ? x : INFINITY;
+    // the thread's buckets: their keys when still in reach, else 0xffffffff
+    unsigned mykey[BF_MAX_BUCKETS / 256];
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < BF_MAX_BUCKETS / 256; e++) {
+      const int b = tid + e * 256;
+      unsigned key = 0xffffffffu;
+      if (b < K0) {
+        const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
+        if (be > bs) {
+          float m;
+          if (bt > 0) {
+            m = l[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
+          } else {
+            const float x = l[b];
+            m = x < INFINITY ? x : INFINITY;
+          }
+          if (m == m) {
+            const unsigned kk = (float_to_bits(m) & ~idx_mask) | (unsigned)b;
+            if ((kk & empty_key) != empty_key && (p.first || kk > done) && (kk & ~idx_mask) <= thr_bits) key = kk;
+          }
+        }
       }
-      if (!(m == m)) continue;
-      const unsigned key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;
-      if ((key & empty_key) != empty_key && key > done && (key & ~idx_mask) <= thr_bits) {
+      mykey[e] = key;
+      mine += key != 0xffffffffu ? 1 : 0;
+    }
+    if (mine) atomicAdd(&s_cnt[0], (unsigned)mine);
+    __syncthreads();
+    const int total = (int)s_cnt[0];
+    unsigned cut = 0xfffffffeu;  // keys <= cut join this round
+    if (p.limit > 0 && total > p.limit) {
+      // the limit-th smallest key in reach (keys are distinct): bisection on its bits
+      unsigned lo = 0u, hi = 0xfffffffeu;
+      while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < BF_MAX_BUCKETS / 256; e++) c += mykey[e] <= mid ? 1 : 0;
+        unsigned *ctr = &s_cnt[1];
+        __syncthreads();
+        if (tid == 0) *ctr = 0u;
+        __syncthreads();
+        if (c) atomicAdd(ctr, (unsigned)c);
+        __syncthreads();
+        if ((int)*ctr >= p.limit) hi = mid;
+        else lo = mid + 1u;
+      }
+      cut = lo;
+      next = cut;
+    }
+#pragma unroll
+    for (int e = 0; e < BF_MAX_BUCKETS / 256; e++) {
+      if (mykey[e] <= cut) {
+        const int b = (int)(mykey[e] & idx_mask);
         atomicOr(&smask[b >> 5], 1u << (b & 31));
         atomicAdd(&p.cnt[b], 1);
       }
     }
-    // the rows pass A found are the first entries of the histogram
+    // the rows found so far are the first entries of the histogram
     if (scale != 0.0f) {
       for (int i = tid; i < p.k; i += blockDim.x) {
         if (p.labels[(size_t)q * p.k + i] >= 0) {
@@ -121,7 +165,137 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   __syncthreads();
   if (tid < nwords) p.mask[(size_t)q * nwords + tid] = smask[tid];
   if (tid < BM_HIST_BINS) p.hist[(size_t)q * BM_HIST_BINS + tid] = shist[tid];
-  if (tid == 0) p.scale[q] = scale;
+  if (tid == 0) {
+    p.scale[q] = scale;
+    p.done_next[q] = next;
+  }
+}
+
+// Instead of a best-first first pass: a threshold per query from a SAMPLE of its nearest rows.  One
+// workgroup per query: the nearest non-empty bucket (smallest key), inside it the nearest non-empty
+// run (smallest second term; the bucket's first row when the rows of a bucket are not ordered), from
+// there up to BM_BOOT_ROWS rows summed completely; their k-th smallest sum has k real rows at or below
+// it -- an upper bound of the final k-th distance (FLT_MAX when the sample has fewer than k rows).
+// The query's result list starts empty and none of its buckets is finished.
+constexpr int BM_BOOT_ROWS = 4096;
+template <int M>
+__global__ __launch_bounds__(256) void bm_boot_kernel(BmParams p) {
+  constexpr int WPR = M / 4;
+  extern __shared__ __attribute__((aligned(16))) float blut[];  // [M * 256]
+  __shared__ unsigned gmin[1 << GMIN_MAX_BITS];
+  __shared__ unsigned s_min, s_cnt;
+  __shared__ unsigned long long s_run;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int K0 = p.n_buckets, bt = p.bucket_t, k = p.k;
+  const float *__restrict__ l = p.lut + (size_t)q * p.lut_floats;
+  for (int e = tid; e < M * 64; e += 256) reinterpret_cast<float4 *>(blut)[e] = reinterpret_cast<const float4 *>(l)[e];
+  for (int i = tid; i < k; i += 256) {
+    p.labels[(size_t)q * k + i] = -1;
+    p.dist[(size_t)q * k + i] = FLT_MAX;
+  }
+  if (tid == 0) {
+    s_min = 0xffffffffu;
+    s_run = ~0ull;
+    p.done_key[q] = 0u;
+  }
+  if (tid < (1 << bt)) gmin[tid] = 0x7f800000u;
+  __syncthreads();
+  if (bt > 0) {
+    const int w = 8 - bt;
+    const int seg = w < 6 ? 1 << w : 64;
+    for (int e0 = tid - lane; e0 < 256; e0 += 256) {
+      const int e = e0 + lane;
+      unsigned v = float_to_bits(blut[256 + e]);
+      for (int o = 1; o < seg; o <<= 1) {
+        const unsigned x = (unsigned)__shfl_xor((int)v, o);
+        v = x < v ? x : v;
+      }
+      if ((lane & (seg - 1)) == 0) atomicMin(&gmin[e >> w], v);
+    }
+    __syncthreads();
+  }
+  const unsigned idx_mask = (unsigned)K0 - 1u;
+  unsigned km = 0xffffffffu;
+  for (int b = tid; b < K0; b += 256) {
+    if (p.bucket_start[b + 1] <= p.bucket_start[b]) continue;
+    float m;
+    if (bt > 0) {
+      m = blut[b >> bt] + bits_to_float(gmin[b & ((1 << bt) - 1)]);
+    } else {
+      const float x = blut[b];
+      m = x < INFINITY ? x : INFINITY;
+    }
+    if (!(m == m)) continue;
+    const unsigned key = (float_to_bits(m) & ~idx_mask) | (unsigned)b;
+    km = key < km ? key : km;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned x = (unsigned)__shfl_xor((int)km, o);
+    km = x < km ? x : km;
+  }
+  if (lane == 0) atomicMin(&s_min, km);
+  __syncthreads();
+  unsigned thr = 0x7f7fffffu;  // FLT_MAX: heap_heapify's neutral (utils/Heap.hpp:211-235)
+  const unsigned kmin = s_min;
+  if (kmin != 0xffffffffu && (kmin & ~idx_mask) < 0x7f800000u) {  // (workgroup-uniform)
+    const int b = (int)(kmin & idx_mask);
+    const int bs = p.bucket_start[b], be = p.bucket_start[b + 1];
+    int rs = bs;
+    if (p.sub_start) {
+      const int R = 256 >> bt;
+      const int f0 = b << (8 - bt), c1base = (b & ((1 << bt) - 1)) << (8 - bt);
+      for (int j = tid; j < R; j += 256) {
+        if (p.sub_start[f0 + j + 1] > p.sub_start[f0 + j])
+          atomicMin(&s_run, ((unsigned long long)float_to_bits(blut[256 + c1base + j]) << 32) | (unsigned)j);
+      }
+      __syncthreads();
+      const unsigned long long best = s_run;
+      if (best != ~0ull) rs = p.sub_start[f0 + (int)(best & 0xffffffffull)];
+    }
+    int r1 = rs + BM_BOOT_ROWS < be ? rs + BM_BOOT_ROWS : be;
+    if (r1 - rs < BM_BOOT_ROWS) rs = r1 - BM_BOOT_ROWS > bs ? r1 - BM_BOOT_ROWS : bs;  // (a short tail: take the rows before it)
+    const int ns = r1 - rs;
+    unsigned v[BM_BOOT_ROWS / 256];
+#pragma unroll
+    for (int e = 0; e < BM_BOOT_ROWS / 256; e++) {
+      const int r = rs + tid + e * 256;
+      unsigned db = 0x7f800000u;
+      if (r < r1) {
+        const uint32_t *rp = p.codes + (int64_t)r * WPR;
+        float acc = 0.0f;
+#pragma unroll
+        for (int gq = 0; gq < WPR; gq++) {
+          const uint32_t c4 = rp[gq];
+          float dism = blut[(gq * 4 + 0) * 256 + (c4 & 0xffu)];
+          dism = dism + blut[(gq * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)];
+          dism = dism + blut[(gq * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)];
+          dism = dism + blut[(gq * 4 + 3) * 256 + (c4 >> 24)];
+          acc = gq == 0 ? dism : acc + dism;
+        }
+        if (acc == acc) db = float_to_bits(acc);  // (sums are >= 0: bit order == value order; NaN counts as +inf)
+      }
+      v[e] = db;
+    }
+    if (ns >= k) {
+      unsigned lo = 0u, hi = 0x7f800000u;  // smallest t with count(v <= t) >= k
+      while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < BM_BOOT_ROWS / 256; e++) c += __popcll(__ballot(v[e] <= mid));
+        __syncthreads();
+        if (tid == 0) s_cnt = 0u;
+        __syncthreads();
+        if (lane == 0 && c) atomicAdd(&s_cnt, (unsigned)c);
+        __syncthreads();
+        if ((int)s_cnt >= k) hi = mid;
+        else lo = mid + 1u;
+      }
+      if (lo < 0x7f800000u) thr = lo < thr ? lo : thr;
+    }
+  }
+  if (tid == 0) p.g_thr[q] = thr;
 }
 
 // One workgroup of 1024 threads: thread b owns bucket b.
@@ -602,9 +776,10 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
         rec.q = q;
         rec.done_key = done;
         rec.thr = thr;
-        rec.pad = 0;
+        rec.pad = p.first;  // (first round: nothing of the query is finished yet)
         p.defer_list[idx] = rec;
       }
+      p.done_key[q] = 0xffffffffu;  // later rounds leave the query alone
     }
     return;
   }
@@ -643,6 +818,11 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
     p.labels[(size_t)q * k + i] = ok ? (int32_t)((int64_t)(int)(unsigned)(key & 0xffffffffull) + p.id_base) : -1;
     p.dist[(size_t)q * k + i] = ok ? bits_to_float((unsigned)(key >> 32)) : FLT_MAX;
   }
+  if (tid == 0) {
+    // the round's buckets are finished; the k-th distance found so far bounds the final one
+    p.done_key[q] = p.done_next[q];
+    if (n >= k) atomicMin(&p.g_thr[q], (unsigned)(sk[k - 1] >> 32));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -659,6 +839,20 @@ size_t scan_bm_lds_bytes(int M, int qb, int nwaves) { return bm_lds_bytes(M, qb,
 size_t bm_plan_small_words(int n_buckets) {
   // cnt, qoff (+1), fill, border, ioff, tickets
   return (size_t)n_buckets * 4 + 1 + (size_t)BM_XCDS * bm_ioff_stride(n_buckets) + BM_XCDS;
+}
+
+hipError_t launch_bm_boot(const BmParams &p, int64_t n_rows, hipStream_t st) {
+  if (p.nq <= 0) return hipSuccess;
+  (void)n_rows;
+  if (p.k > BM_BOOT_ROWS) return hipErrorInvalidValue;
+  const size_t lds = (size_t)p.M * 256 * sizeof(float);
+  switch (p.M) {
+  case 8: hipLaunchKernelGGL(bm_boot_kernel<8>, dim3(p.nq), dim3(256), lds, st, p); break;
+  case 16: hipLaunchKernelGGL(bm_boot_kernel<16>, dim3(p.nq), dim3(256), lds, st, p); break;
+  case 32: hipLaunchKernelGGL(bm_boot_kernel<32>, dim3(p.nq), dim3(256), lds, st, p); break;
+  default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_bm_plan(const BmParams &p, hipStream_t st) {

@@ -134,7 +134,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0, opt_sub_order = 1, opt_bm_sub = 1;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0, opt_sub_order = 1, opt_bm_sub = 1, opt_bm_boot = 1, opt_bm_round = 6;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -505,8 +505,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     HIP_TRY(ix->w_bm_qlist.ensure((size_t)chunk * K0 * sizeof(int)));
     HIP_TRY(ix->w_bm_cand_d.ensure((size_t)chunk * pl.bm_cap * sizeof(float)));
     HIP_TRY(ix->w_bm_cand_id.ensure((size_t)chunk * pl.bm_cap * sizeof(int)));
-    // per query: done_key, candidate count, scale, histogram
-    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (3 + vaq::BM_HIST_BINS) * 4));
+    // per query: done_key, candidate count, scale, next done_key, histogram
+    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (4 + vaq::BM_HIST_BINS) * 4));
     // overflowed queries are finished by the best-first form's second launch
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)chunk * sizeof(vaq::DeferRec)));
     HIP_TRY(ix->w_part_d.ensure((size_t)chunk * DEFER_SLICES * k * sizeof(float)));
@@ -744,7 +744,10 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       bp.done_key = qw;
       bp.cand_cnt = qw + (size_t)chunk;
       bp.scale = reinterpret_cast<float *>(qw + (size_t)2 * chunk);
-      bp.hist = qw + (size_t)3 * chunk;
+      bp.done_next = qw + (size_t)3 * chunk;
+      bp.hist = qw + (size_t)4 * chunk;
+      bp.first = 0;
+      bp.limit = 0;
       bp.mask = ix->w_bm_mask.as<unsigned>();
       {
         int *sm = ix->w_bm_small.as<int>();
@@ -774,12 +777,30 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       sp.defer_list = reinterpret_cast<vaq::DeferRec *>(ix->w_defer.as<unsigned char>() + 16);
       HIP_TRY(hipMemsetAsync(sp.defer_count, 0, sizeof(unsigned), st));
     }
-    if (ix->N > 0) HIP_TRY(vaq::launch_scan(sp, &grid, st));
+    const bool bm_boot = bm && ix->opt_bm_boot;
+    if (bm_boot) {
+      // no best-first pass: a threshold per query from a sample of its nearest rows, then the
+      // nearest bucket of every query is the first bucket-major round
+      HIP_TRY(vaq::launch_bm_boot(bp, ix->N, st));
+    } else if (ix->N > 0) {
+      HIP_TRY(vaq::launch_scan(sp, &grid, st));
+    }
     if (bm) {
-      // plan, pass B, select (vaq_scan_bm.hip); queries whose candidate buffer overflowed join the defer list
-      HIP_TRY(vaq::launch_bm_plan(bp, st));
-      HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
-      HIP_TRY(vaq::launch_bm_select(bp, st));
+      // rounds of plan, scan, select (vaq_scan_bm.hip): each query's nearest bucket [after a sampled
+      // threshold], its next few, then everything still in reach -- thresholds are near their final
+      // values before the bulk of the rows is met.  Queries whose candidate buffer overflows join
+      // the defer list.
+      int limits[3], nr = 0;
+      if (bm_boot) limits[nr++] = 1;
+      if (ix->opt_bm_round > 0) limits[nr++] = ix->opt_bm_round;
+      limits[nr++] = 0;
+      for (int r = 0; r < nr; r++) {
+        bp.first = (bm_boot && r == 0) ? 1 : 0;
+        bp.limit = limits[r];
+        HIP_TRY(vaq::launch_bm_plan(bp, st));
+        HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
+        HIP_TRY(vaq::launch_bm_select(bp, st));
+      }
       if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what pass A handed over and what pass B appended
         std::vector<unsigned> hq((size_t)3 * chunk), hthr((size_t)n);
         std::vector<int> hcnt((size_t)ix->n_buckets);
@@ -1656,6 +1677,11 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "defer_units") {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
+  } else if (k == "bm_boot") {
+    ix->opt_bm_boot = value != 0;
+  } else if (k == "bm_round") {
+    if (value < 0 || value > 1024) return fail(VAQHIP_EINVAL, "bm_round must be 0..1024 buckets");
+    ix->opt_bm_round = (int)value;
   } else if (k == "bm_runs") {
     ix->opt_bm_sub = value != 0;  // 0: the bucket-major pass ignores the order inside the buckets (every row of a bucket read)
   } else if (k == "sub_order") {
