@@ -337,8 +337,9 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       queries' lookup tables at a time in LDS, instead of once per query
  *                       ("Bucket-major second pass"); 0: off; 2: whenever a
  *                       kernel exists (tests).  Results are identical.
- *   "bm_candidates"     slots of a query's candidate buffer in that pass (default 2048); a query that
- *                       overflows it is finished by the best-first form
+ *   "bm_candidates"     slots of a query's candidate buffer in that pass (default 4096); a query that
+ *                       overflows it tries the same buckets again under the threshold the stored rows
+ *                       give, and is finished by the best-first form if that overflows too
  *   "bm_units"          work units (64 wave steps) of the first pass per query; 0 = about one
  *                       average bucket
  *   "bm_boot"           1 (default): no best-first pass at all -- every query gets a threshold from a

@@ -231,8 +231,11 @@ struct BmParams {
   unsigned *g_thr;           // [nq] float bits: thresholds (rows AT them stay admissible)
   unsigned *done_key;        // [nq] buckets with keys <= this are finished; 0xffffffff: the query is complete
   unsigned *done_next;       // [nq] what done_key becomes when the round's select succeeds
-  int first;                 // 1: no bucket is finished yet (done_key is ignored: the round after launch_bm_boot)
+  unsigned *fresh;           // [nq] 1: no bucket of the query is finished yet (done_key is ignored: set by
+                             //      launch_bm_boot, cleared by the query's first successful select)
   int limit;                 // buckets a query takes in this round, nearest first (<= 0: all in reach)
+  int retry;                 // 1: a query whose candidate buffer overflows only gets a tighter threshold from what was
+                             //    stored and tries the same buckets again next round; 0 (last round): defer list
   // plan (device, written by launch_bm_plan)
   unsigned *mask;            // [nq][n_buckets / 32] buckets still in reach
   int *cnt;                  // [n_buckets] queries per bucket

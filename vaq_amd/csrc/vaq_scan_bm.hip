@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   const int K0 = p.n_buckets, bt = p.bucket_t;
   const int nwords = K0 / 32;
   const unsigned done = p.done_key[q];
+  const bool fresh = p.fresh[q] != 0u;
   if (tid == 0) p.cand_cnt[q] = 0u;
   if (tid < BM_HIST_BINS) shist[tid] = 0u;
   if (tid < nwords) smask[tid] = 0u;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
           }
           if (m == m) {
             const unsigned kk = (float_to_bits(m) & ~idx_mask) | (unsigned)b;
-            if ((kk & empty_key) != empty_key && (p.first || kk > done) && (kk & ~idx_mask) <= thr_bits) key = kk;
+            if ((kk & empty_key) != empty_key && (fresh || kk > done) && (kk & ~idx_mask) <= thr_bits) key = kk;
           }
         }
       }
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void bm_boot_kernel(BmParams p) {
     s_min = 0xffffffffu;
     s_run = ~0ull;
     p.done_key[q] = 0u;
+    p.fresh[q] = 1u;
   }
   if (tid < (1 << bt)) gmin[tid] = 0x7f800000u;
   __syncthreads();
@@ -765,10 +767,13 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
   const int q = blockIdx.x, tid = threadIdx.x, k = p.k;
   const unsigned done = p.done_key[q];
   if (done == 0xffffffffu) return;  // pass A finished this query: its list is the result
-  const unsigned cnt = p.cand_cnt[q];
+  const unsigned cnt_all = p.cand_cnt[q];
   const unsigned thr = p.g_thr[q];
-  if (cnt > (unsigned)p.cap) {
-    // more candidates than slots: the best-first form finishes this query on its own
+  const bool over = cnt_all > (unsigned)p.cap;
+  const unsigned cnt = over ? (unsigned)p.cap : cnt_all;
+  if (over && !p.retry) {
+    // more candidates than slots, and no round left to try again: the best-first form finishes this
+    // query on its own
     if (tid == 0) {
       const unsigned idx = atomicAdd(p.defer_count, 1u);
       if (idx < (unsigned)p.defer_cap) {
@@ -776,7 +781,7 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
         rec.q = q;
         rec.done_key = done;
         rec.thr = thr;
-        rec.pad = p.first;  // (first round: nothing of the query is finished yet)
+        rec.pad = (int)p.fresh[q];  // (nothing of the query is finished yet)
         p.defer_list[idx] = rec;
       }
       p.done_key[q] = 0xffffffffu;  // later rounds leave the query alone
@@ -812,6 +817,13 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
       }
       __syncthreads();
     }
+  if (over) {
+    // More candidates than slots: the stored ones are still real rows, so the k-th smallest key here
+    // bounds the final k-th distance.  Nothing else is kept -- the list and done_key stay as they
+    // were, and the NEXT round plans the same buckets again under the tighter threshold.
+    if (tid == 0 && n >= k) atomicMin(&p.g_thr[q], (unsigned)(sk[k - 1] >> 32));
+    return;
+  }
   for (int i = tid; i < k; i += BM_SELECT_THREADS) {
     const bool ok = i < n;
     const unsigned long long key = ok ? sk[i] : 0ull;
@@ -821,6 +833,7 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
   if (tid == 0) {
     // the round's buckets are finished; the k-th distance found so far bounds the final one
     p.done_key[q] = p.done_next[q];
+    p.fresh[q] = 0u;
     if (n >= k) atomicMin(&p.g_thr[q], (unsigned)(sk[k - 1] >> 32));
   }
 }

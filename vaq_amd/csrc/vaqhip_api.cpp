@@ -91,7 +91,7 @@ constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to w
 // bucket is wanted by several of them.  Pass A (best-first, one workgroup per query) is cut after
 // about one average bucket's worth of work units; BM_CAND_CAP candidate slots per query.
 constexpr int BM_MIN_QUERIES = 512;
-constexpr int BM_CAND_CAP = 2048;
+constexpr int BM_CAND_CAP = 4096;
 constexpr int BM_QB = 4, BM_NWAVES = 16;
 
 } // namespace
@@ -505,8 +505,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     HIP_TRY(ix->w_bm_qlist.ensure((size_t)chunk * K0 * sizeof(int)));
     HIP_TRY(ix->w_bm_cand_d.ensure((size_t)chunk * pl.bm_cap * sizeof(float)));
     HIP_TRY(ix->w_bm_cand_id.ensure((size_t)chunk * pl.bm_cap * sizeof(int)));
-    // per query: done_key, candidate count, scale, next done_key, histogram
-    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (4 + vaq::BM_HIST_BINS) * 4));
+    // per query: done_key, candidate count, scale, next done_key, fresh, histogram
+    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (5 + vaq::BM_HIST_BINS) * 4));
     // overflowed queries are finished by the best-first form's second launch
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)chunk * sizeof(vaq::DeferRec)));
     HIP_TRY(ix->w_part_d.ensure((size_t)chunk * DEFER_SLICES * k * sizeof(float)));
@@ -745,9 +745,11 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       bp.cand_cnt = qw + (size_t)chunk;
       bp.scale = reinterpret_cast<float *>(qw + (size_t)2 * chunk);
       bp.done_next = qw + (size_t)3 * chunk;
-      bp.hist = qw + (size_t)4 * chunk;
-      bp.first = 0;
+      bp.fresh = qw + (size_t)4 * chunk;
+      bp.hist = qw + (size_t)5 * chunk;
       bp.limit = 0;
+      bp.retry = 0;
+      HIP_TRY(hipMemsetAsync(bp.fresh, 0, (size_t)n * 4, st));
       bp.mask = ix->w_bm_mask.as<unsigned>();
       {
         int *sm = ix->w_bm_small.as<int>();
@@ -790,18 +792,22 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       // threshold], its next few, then everything still in reach -- thresholds are near their final
       // values before the bulk of the rows is met.  Queries whose candidate buffer overflows join
       // the defer list.
-      int limits[3], nr = 0;
+      // A query whose candidate buffer overflows in a round keeps its place: what was stored tightens
+      // its threshold and the next round plans the same buckets again; one more round (nothing to do
+      // when no buffer overflowed) gives the last regular round that second try too, and only what
+      // overflows THERE is left to the best-first form.
+      int limits[4], nr = 0;
       if (bm_boot) limits[nr++] = 1;
       if (ix->opt_bm_round > 0) limits[nr++] = ix->opt_bm_round;
       limits[nr++] = 0;
+      limits[nr++] = 0;
       for (int r = 0; r < nr; r++) {
-        bp.first = (bm_boot && r == 0) ? 1 : 0;
+        bp.retry = r + 1 < nr ? 1 : 0;
         bp.limit = limits[r];
         HIP_TRY(vaq::launch_bm_plan(bp, st));
         HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
         HIP_TRY(vaq::launch_bm_select(bp, st));
-      }
-      if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what pass A handed over and what pass B appended
+        if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what pass A handed over and what pass B appended
         std::vector<unsigned> hq((size_t)3 * chunk), hthr((size_t)n);
         std::vector<int> hcnt((size_t)ix->n_buckets);
         HIP_TRY(hipStreamSynchronize(st));
@@ -823,11 +829,12 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
           groups += g;
           work += g * (unsigned long long)(hb[b + 1] - hb[b]);
         }
-        std::fprintf(stderr, "[VAQHIP_BM_DEBUG] queries %d handed over %llu; (query, bucket) pairs %llu, items %llu, row-steps x QB "
+        std::fprintf(stderr, "[VAQHIP_BM_DEBUG] round %d (limit %d): queries %d still open after it %llu; (query, bucket) pairs %llu, items %llu, row-steps x QB "
                              "%.3e (= %.2f %% of rows per query slot); candidates appended %llu (max %llu per query), overflowed "
                              "queries %llu; pass A units %d\n",
-                     n, handed, pairs, groups, (double)work * pl.bm_qb, 100.0 * (double)work * pl.bm_qb / ((double)n * (double)ix->N),
+                     r, limits[r], n, handed, pairs, groups, (double)work * pl.bm_qb, 100.0 * (double)work * pl.bm_qb / ((double)n * (double)ix->N),
                      appended, maxc, over, pl.defer_units);
+      }
       }
     }
     if (defer || bm) {
@@ -1690,7 +1697,7 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "bucket_major must be 0 (off), 1 (automatic) or 2 (whenever a kernel exists)");
     ix->opt_bm = (int)value;
   } else if (k == "bm_candidates") {
-    if (value < 0 || value > 4096) return fail(VAQHIP_EINVAL, "bm_candidates must be 0 (default) or 1..4096");
+    if (value < 0 || value > 7168) return fail(VAQHIP_EINVAL, "bm_candidates must be 0 (default) or 1..7168");
     ix->opt_bm_cap = (int)value;
   } else if (k == "bm_units") {
     if (value < 0 || value > (1 << 20)) return fail(VAQHIP_EINVAL, "bm_units must be 0 (automatic) or a number of work units");
