@@ -330,7 +330,7 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       effect when the codes are (re)set
  *   "bucket_skip"       1 (default); 0 visits every bucket -- for measuring the streaming
  *                       rate of the scan, results are the same                             */
-/*   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 512
+/*   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 128
  *                       queries in the call, the best-first pass is cut after each query's nearest
  *                       buckets and what is left in reach is scanned bucket by bucket: a bucket's
  *                       rows are streamed once for ALL the queries that still want it, four
@@ -342,9 +342,10 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       give, and is finished by the best-first form if that overflows too
  *   "bm_units"          work units (64 wave steps) of the first pass per query; 0 = about one
  *                       average bucket
- *   "bm_boot"           1 (default): no best-first pass at all -- every query gets a threshold from a
+ *   "bm_boot"           2: no best-first pass at all -- every query gets a threshold from a
  *                       sample of its nearest rows, and its nearest bucket is the first bucket-major
- *                       round; 0: the capped best-first pass ("bm_units") comes first
+ *                       round; 0: a capped best-first pass ("bm_units") comes first; 1 (default):
+ *                       the former when buckets are large (>= 24 work units on average)
  *   "bm_round"          buckets per query of the middle round (default 6, 0 = no middle round): after
  *                       it the thresholds are near their final values, and the last round -- every
  *                       bucket still in reach -- meets far fewer rows

@@ -69,7 +69,7 @@ def test_bucket_major_matches_oracle(vaqlib, oracle, seed, bits, N, nq, k, bb, k
     shapes = [(0, 0, 0, 0, 6), (0, 0, 4, 16, 0), (0, 8, 2, 8, 1), (0, 64, 4, 4, 3), (0, 1, 0, 0, 2),
               (1, 0, 4, 16, 0), (1, 0, 2, 8, 2), (4, 0, 4, 4, 6), (1, 8, 4, 16, 0), (2, 64, 2, 16, 1), (100000, 0, 0, 0, 0)]
     for units, cap, qb, nw, rnd in shapes:
-        l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=0 if units else 1, bm_units=units, bm_candidates=cap,
+        l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=0 if units else 2, bm_units=units, bm_candidates=cap,
                       bm_queries_per_group=qb, bm_waves=nw, bm_round=rnd)
         seen += t["bucket_major"]
         what = f"units={units} cap={cap} qb={qb} nw={nw} round={rnd}"
@@ -79,7 +79,7 @@ def test_bucket_major_matches_oracle(vaqlib, oracle, seed, bits, N, nq, k, bb, k
     assert seen == len(shapes)
     # the order inside the buckets (rows of a bucket sorted by the second code; the pass skips whole
     # runs) is invisible: pass with the runs ignored, and an index built without that order
-    for boot in (0, 1):
+    for boot in (0, 2):
         l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=boot, bm_units=1, bm_candidates=0, bm_queries_per_group=0,
                       bm_waves=0, bm_runs=0, bm_round=6)
         assert t["bucket_major"] == 1 and np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l)
@@ -99,7 +99,7 @@ def test_bucket_major_overflow_and_small_k(vaqlib, oracle):
         v = make_index(c)
         v.set_option("timing", 1)
         base_l, base_d, _ = run(v, c["X"], k, bucket_major=0)
-        for cap, boot in ((1, 0), (0, 0), (1, 1), (0, 1)):
+        for cap, boot in ((1, 0), (0, 0), (1, 2), (0, 2)):
             l, d, t = run(v, c["X"], k, bucket_major=2, bm_units=1, bm_candidates=cap, bm_boot=boot)
             assert t["bucket_major"] == 1
             assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32)) and np.array_equal(l, base_l), (k, cap, boot)
@@ -127,7 +127,7 @@ def test_bucket_major_encoded_clustered(vaqlib, oracle):
     v = make_index(c, 10)
     v.set_option("timing", 1)
     base_l, base_d, t0 = run(v, c["X"], k, bucket_major=0)
-    for boot in (1, 0):
+    for boot in (2, 0, 1):
         l, d, t = run(v, c["X"], k, bucket_major=2, bm_boot=boot)
         assert t["bucket_major"] == 1 and t0["bucket_major"] == 0
         assert np.array_equal(d.view(np.uint32), base_d.view(np.uint32))
@@ -163,7 +163,7 @@ def test_bucket_major_after_appends(vaqlib, oracle):
         v.add_codes(c["codes"][250_000:340_000])
         v.add_codes(c["codes"][340_000:])
         v.set_option("timing", 1)
-        for bm, boot in ((0, 0), (2, 0), (2, 1)):
+        for bm, boot in ((0, 0), (2, 0), (2, 2)):
             l, d, t = run(v, c["X"], k, bucket_major=bm, bm_units=1, bm_boot=boot)
             assert t["bucket_major"] == (1 if bm else 0)
             res[(sub_order, bm, boot)] = (l, d)

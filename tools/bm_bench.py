@@ -73,7 +73,7 @@ def main():
     if a.units:
         shapes = [dict(bucket_major=2, bm_boot=0, bm_units=int(u)) for u in a.units.split(",")]
     if a.rounds:  # "boot:round" pairs, e.g. 1:6,1:0,0:6
-        shapes = [dict(bucket_major=2, bm_boot=int(x.split(":")[0]), bm_round=int(x.split(":")[1])) for x in a.rounds.split(",")]
+        shapes = [dict(bucket_major=2, bm_boot=2 * int(x.split(":")[0]), bm_round=int(x.split(":")[1])) for x in a.rounds.split(",")]
     if a.sweep:
         shapes += [dict(bucket_major=2, bm_units=u) for u in (8, 32, 128, 512)]
         shapes += [dict(bucket_major=2, bm_units=0, bm_queries_per_group=2), dict(bucket_major=2, bm_queries_per_group=4, bm_waves=8)]

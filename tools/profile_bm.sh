@@ -14,6 +14,13 @@ mkdir -p $out
 ARGS="--rows $rows --skip-base --steps 3 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 tools/bm_bench.py $ARGS > $out/kt_bench.txt 2> $out/kt.err || { tail -5 $out/kt.err; exit 1; }
 cp $(find $out/kt -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+python3 - "$(find $out/kt -name '*kernel_trace.csv' | head -1)" > $out/scan_dispatches.txt <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"]
+    if "scan_b" in n or "bm_" in n:
+        print(n.split("(")[0].replace("void vaq::", "").replace("vaq::", ""), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, "ms")
+PY
 rm -rf $out/kt
 echo "kernel trace done"; grep -E "scan_|bm_|merge|lut_|project|cost|Name" $out/kernel_stats.csv | cut -c1-200 | head -20
 tail -3 $out/kt_bench.txt

@@ -228,7 +228,12 @@ struct BmParams {
   int lut_floats;
   int nq, k, qb;
   int nwaves;
-  unsigned *g_thr;           // [nq] float bits: thresholds (rows AT them stay admissible)
+  unsigned *g_thr;           // [nq] float bits: thresholds of the best-first form (rows AT them stay admissible):
+                             //      what a best-first first pass leaves, and what its second launch (overflow) starts from
+  unsigned long long *thr64; // [nq] the rounds' thresholds: distance bits << 32 | label bound -- a row is a candidate iff
+                             //      its (distance bits << 32 | label) is BELOW this word; label bound 0x7fffffff keeps every
+                             //      row at that distance.  init64: bm_mark sets it from g_thr first (a search's first round)
+  int init64;
   unsigned *done_key;        // [nq] buckets with keys <= this are finished; 0xffffffff: the query is complete
   unsigned *done_next;       // [nq] what done_key becomes when the round's select succeeds
   unsigned *fresh;           // [nq] 1: no bucket of the query is finished yet (done_key is ignored: set by

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   if (tid < BM_HIST_BINS) shist[tid] = 0u;
   if (tid < nwords) smask[tid] = 0u;
   if (tid < 2) s_cnt[tid] = 0u;
-  const unsigned thr_bits = p.g_thr[q];
+  // (a search's first round: the word starts from what the first pass / the sample left in g_thr)
+  const unsigned long long t64 = p.init64 ? (((unsigned long long)p.g_thr[q] << 32) | 0x7fffffffull) : p.thr64[q];
+  if (p.init64 && tid == 0) p.thr64[q] = t64;
+  const unsigned thr_bits = (unsigned)(t64 >> 32);
   const float H = bits_to_float(thr_bits);
   const float scale = (done != 0xffffffffu && H > 0.0f && H < FLT_MAX) ? (float)BM_HIST_BINS / H : 0.0f;
   unsigned next = 0xffffffffu;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         //  indexed by a lane value ends up in scratch memory)
         const int myq = p.qlist[qbase + (tid < nact ? tid : 0)];
         s_q[tid] = myq;
-        s_thr[tid] = tid < nact ? __hip_atomic_load(&p.g_thr[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        s_thr[tid] = tid < nact ? (unsigned)(__hip_atomic_load(&p.thr64[myq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32)
                                 : 0xbf800000u;  // -1: nothing passes (a slot past the end of the bucket's list)
       }
       __syncthreads();
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         if ((kstep & (BM_THR_EVERY - 1)) != 0) return;
         if (wave == 0 && (kstep & (BM_THR_GLOBAL_EVERY - 1)) == 0 && kstep > 0) {
           if (lane < nact) {
-            const unsigned gt = __hip_atomic_load(&p.g_thr[pick_q(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned gt = (unsigned)(__hip_atomic_load(&p.thr64[pick_q(lane)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
             atomicMin(&s_thr[lane], gt);
           }
           wave_lds_sync();
@@ -555,9 +558,17 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         int q = 0;
         float sc = 0.0f;
         bool trig = false;
+        bool ok2 = ok;
+        int label = 0;
         if (ok) {
+          // the exact test, on (distance, label): the shared word may hold a label bound (after an
+          // overflow among rows of EQUAL distance only the smallest labels are wanted)
           q = pick_q(i);
-          const int label = perm ? (int)perm[row] : row;  // labels are ORIGINAL rows
+          label = perm ? (int)perm[row] : row;  // labels are ORIGINAL rows
+          const unsigned long long t64 = __hip_atomic_load(&p.thr64[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok2 = (((unsigned long long)float_to_bits(d) << 32) | (unsigned)label) < t64;
+        }
+        if (ok2) {
           const unsigned pos = atomicAdd(&p.cand_cnt[q], 1u);
           sc = p.scale[q];
           if (sc != 0.0f) {
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
             if (jb < BM_HIST_BINS - 1) {  // (the last bin also holds everything beyond H)
               const float edge = ((float)(jb + 1) / scq) * (1.0f + 1.0f / 1048576.0f);
               if (lane == 0) {
-                atomicMin(&p.g_thr[qq], float_to_bits(edge));
+                atomicMin(&p.thr64[qq], ((unsigned long long)float_to_bits(edge) << 32) | 0x7fffffffull);
                 atomicMin(&s_thr[ii], float_to_bits(edge));
               }
             }
@@ -768,7 +779,8 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
   const unsigned done = p.done_key[q];
   if (done == 0xffffffffu) return;  // pass A finished this query: its list is the result
   const unsigned cnt_all = p.cand_cnt[q];
-  const unsigned thr = p.g_thr[q];
+  const unsigned long long t64 = p.thr64[q];
+  const unsigned thr = (unsigned)(t64 >> 32);
   const bool over = cnt_all > (unsigned)p.cap;
   const unsigned cnt = over ? (unsigned)p.cap : cnt_all;
   if (over && !p.retry) {
@@ -783,6 +795,7 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
         rec.thr = thr;
         rec.pad = (int)p.fresh[q];  // (nothing of the query is finished yet)
         p.defer_list[idx] = rec;
+        atomicMin(&p.g_thr[q], thr);  // (the word its workgroups share)
       }
       p.done_key[q] = 0xffffffffu;  // later rounds leave the query alone
     }
@@ -797,9 +810,9 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
                                 (unsigned)((int64_t)lab - p.id_base);
   }
   for (unsigned i = tid; i < cnt; i += BM_SELECT_THREADS) {
-    const unsigned db = float_to_bits(p.cand_d[(size_t)q * p.cap + i]);
-    if (db <= thr)  // (distances are >= 0: bit order == value order; rows AT the threshold stay)
-      sk[atomicAdd(&s_n, 1u)] = ((unsigned long long)db << 32) | (unsigned)p.cand_id[(size_t)q * p.cap + i];
+    const unsigned long long key = ((unsigned long long)float_to_bits(p.cand_d[(size_t)q * p.cap + i]) << 32) |
+                                   (unsigned)p.cand_id[(size_t)q * p.cap + i];
+    if (key < t64) sk[atomicAdd(&s_n, 1u)] = key;  // (distances are >= 0: bit order == value order)
   }
   __syncthreads();
   const int n = (int)s_n;
@@ -821,7 +834,9 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
     // More candidates than slots: the stored ones are still real rows, so the k-th smallest key here
     // bounds the final k-th distance.  Nothing else is kept -- the list and done_key stay as they
     // were, and the NEXT round plans the same buckets again under the tighter threshold.
-    if (tid == 0 && n >= k) atomicMin(&p.g_thr[q], (unsigned)(sk[k - 1] >> 32));
+    // (the bound is the k-th pair itself, label included -- among rows of EQUAL distance only the
+    //  smallest labels are wanted, or a query with thousands of identical rows would overflow for ever)
+    if (tid == 0 && n >= k) atomicMin(&p.thr64[q], sk[k - 1] + 1ull);
     return;
   }
   for (int i = tid; i < k; i += BM_SELECT_THREADS) {
@@ -834,7 +849,7 @@ __global__ __launch_bounds__(BM_SELECT_THREADS) void bm_select_kernel(BmParams p
     // the round's buckets are finished; the k-th distance found so far bounds the final one
     p.done_key[q] = p.done_next[q];
     p.fresh[q] = 0u;
-    if (n >= k) atomicMin(&p.g_thr[q], (unsigned)(sk[k - 1] >> 32));
+    if (n >= k) atomicMin(&p.thr64[q], sk[k - 1] + 1ull);
   }
 }
 

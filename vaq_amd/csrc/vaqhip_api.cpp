@@ -90,9 +90,10 @@ constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to w
 // Bucket-major second pass (vaq_scan_bm.hip): a streamed database and so many queries that every
 // bucket is wanted by several of them.  Pass A (best-first, one workgroup per query) is cut after
 // about one average bucket's worth of work units; BM_CAND_CAP candidate slots per query.
-constexpr int BM_MIN_QUERIES = 512;
+constexpr int BM_MIN_QUERIES = 128;
 constexpr int BM_CAND_CAP = 4096;
 constexpr int BM_QB = 4, BM_NWAVES = 16;
+constexpr int BM_BOOT_MIN_UNITS = 24;
 
 } // namespace
 
@@ -124,7 +125,7 @@ struct vaqhip_index {
   DevBuf w_cost;   // [nq] cost keys of launch_cost_order
   DevBuf w_defer;  // [0] entries asked for, then DEFER_CAP records (best-first form, queries cut in two)
   // bucket-major second pass: plan arrays, per-bucket query lists, candidates, per-query words
-  DevBuf w_bm_small, w_bm_mask, w_bm_qlist, w_bm_cand_d, w_bm_cand_id, w_bm_query;
+  DevBuf w_bm_small, w_bm_mask, w_bm_qlist, w_bm_cand_d, w_bm_cand_id, w_bm_query, w_bm_thr64;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
   // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
@@ -172,7 +173,8 @@ struct Plan {
   int bf_pool = 0;
   int defer_units = 0;  // > 0: expensive queries are cut in two (ScanParams::defer_*)
   bool cost_order = false;  // one best-first workgroup per query: expensive queries are dispatched first
-  bool bm = false;          // bucket-major second pass behind a capped best-first pass (vaq_scan_bm.hip)
+  bool bm = false;          // bucket-major rounds (vaq_scan_bm.hip)
+  bool bm_boot = false;     //   thresholds from a sample instead of a capped best-first pass
   int bm_qb = 0, bm_nwaves = 0, bm_cap = 0;
 };
 
@@ -368,8 +370,14 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
         // pass A: about one average bucket per query (a work unit = 64 wave steps)
         const int64_t unit_rows = 64 * (int64_t)(vaq::scan_wg_step_rows(ix->layout, ix->M) / vaq::SCAN_MAX_WAVES);
         const int64_t avg = N / ix->n_buckets + 1;
+        const int64_t bucket_units = (avg + unit_rows - 1) / unit_rows;
         pl->defer_units = ix->opt_bm_units > 0 ? ix->opt_bm_units
-                                               : (int)std::min<int64_t>(4096, std::max<int64_t>(8, (avg + unit_rows - 1) / unit_rows));
+                                               : (int)std::min<int64_t>(4096, std::max<int64_t>(8, bucket_units));
+        // Small buckets: a best-first pass over each query's nearest one is cheap and leaves a better
+        // threshold than a sample (100M x 8 B, 10 k queries: 9.4 ms against 13.8).  Large buckets: that
+        // pass streams 10 k buckets from HBM with nothing shared (1B x 16 B: 63 ms of 161), so a
+        // sampled threshold and the nearest bucket as the first bucket-major round (11 ms).
+        pl->bm_boot = ix->opt_bm_boot == 1 ? bucket_units >= BM_BOOT_MIN_UNITS : ix->opt_bm_boot != 0;
       }
     }
   }
@@ -507,6 +515,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     HIP_TRY(ix->w_bm_cand_id.ensure((size_t)chunk * pl.bm_cap * sizeof(int)));
     // per query: done_key, candidate count, scale, next done_key, fresh, histogram
     HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (5 + vaq::BM_HIST_BINS) * 4));
+    HIP_TRY(ix->w_bm_thr64.ensure((size_t)chunk * sizeof(unsigned long long)));
     // overflowed queries are finished by the best-first form's second launch
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)chunk * sizeof(vaq::DeferRec)));
     HIP_TRY(ix->w_part_d.ensure((size_t)chunk * DEFER_SLICES * k * sizeof(float)));
@@ -741,6 +750,8 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       bp.qb = pl.bm_qb;
       bp.nwaves = pl.bm_nwaves;
       bp.g_thr = sp.g_thr;
+      bp.thr64 = ix->w_bm_thr64.as<unsigned long long>();
+      bp.init64 = 0;
       bp.done_key = qw;
       bp.cand_cnt = qw + (size_t)chunk;
       bp.scale = reinterpret_cast<float *>(qw + (size_t)2 * chunk);
@@ -779,7 +790,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       sp.defer_list = reinterpret_cast<vaq::DeferRec *>(ix->w_defer.as<unsigned char>() + 16);
       HIP_TRY(hipMemsetAsync(sp.defer_count, 0, sizeof(unsigned), st));
     }
-    const bool bm_boot = bm && ix->opt_bm_boot;
+    const bool bm_boot = bm && pl.bm_boot;
     if (bm_boot) {
       // no best-first pass: a threshold per query from a sample of its nearest rows, then the
       // nearest bucket of every query is the first bucket-major round
@@ -804,6 +815,7 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
       for (int r = 0; r < nr; r++) {
         bp.retry = r + 1 < nr ? 1 : 0;
         bp.limit = limits[r];
+        bp.init64 = r == 0 ? 1 : 0;
         HIP_TRY(vaq::launch_bm_plan(bp, st));
         HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
         HIP_TRY(vaq::launch_bm_select(bp, st));
@@ -1685,7 +1697,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
   } else if (k == "bm_boot") {
-    ix->opt_bm_boot = value != 0;
+    if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "bm_boot must be 0 (never), 1 (automatic) or 2 (always)");
+    ix->opt_bm_boot = (int)value;
   } else if (k == "bm_round") {
     if (value < 0 || value > 1024) return fail(VAQHIP_EINVAL, "bm_round must be 0..1024 buckets");
     ix->opt_bm_round = (int)value;
