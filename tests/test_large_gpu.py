@@ -180,21 +180,39 @@ def test_c5_cut_64m_rows(vaqlib, oracle):
     del host
     check_forms(v, c, Xd, k, base, [(1, 1, 0, 1, 16), (2, 1, 0, 1, 16), (2, 2, 0, 1, 16), (4, 2, 0, 0, 16),
                                     (1, 2, 0, 1, 0), (4, 1, 0, 0, 16), (2, 0, 0, 1, 16), (4, 1, 1000, 1, 16)])
-    # many queries: the library switches to the best-first form (one query per workgroup, several
-    # slices per query, thresholds exchanged between them); same answers as the shared-stream forms
-    big = np.concatenate([c["X"]] * 8)[:200] + np.float32(0)
+    # many queries: the library switches to the bucket-major rounds (vaq_scan_bm.hip: every bucket
+    # streamed once for all the queries that reach it); same answers as the shared-stream forms, as
+    # the best-first form (one query per workgroup, several slices per query, thresholds exchanged
+    # between them) and as the rounds in every shape
+    big = np.concatenate([c["X"]] * 8)[:240] + np.float32(0)
     bigd = torch.from_numpy(np.ascontiguousarray(big)).cuda()
     v.set_option("timing", 1)
     lb_, db_ = search_np(v, bigd, k)
     tb = v.last_timing()
-    v.set_option("timing", 0)
-    assert tb["best_first"] == 1 and tb["queries_per_pass"] == 1 and tb["slices"] > 1, tb
-    for j in range(200):
+    assert tb["bucket_major"] == 1 and tb["queries_per_pass"] == 1 and tb["slices"] == 1, tb
+    for j in range(240):
         assert np.array_equal(lb_[j], base[0][j % 32]) and np.array_equal(db_[j], base[1][j % 32]), j
+    v.set_option("bucket_major", 0)
+    l1_, d1_ = search_np(v, bigd, k)
+    t1 = v.last_timing()
+    assert t1["bucket_major"] == 0 and t1["best_first"] == 1 and t1["queries_per_pass"] == 1 and t1["slices"] > 1, t1
+    assert np.array_equal(l1_, lb_) and np.array_equal(d1_, db_)
     v.set_option("best_first", 0)
     l0_, d0_ = search_np(v, bigd, k)
     assert np.array_equal(l0_, lb_) and np.array_equal(d0_, db_)
     v.set_option("best_first", 1)
+    v.set_option("bucket_major", 1)
+    for opts in (dict(bm_boot=0), dict(bm_boot=2, bm_round=0), dict(bm_boot=2, bm_round=2, bm_candidates=64),
+                 dict(bm_boot=0, bm_units=4, bm_runs=0), dict(bm_queries_per_group=2, bm_waves=8)):
+        for key, val in opts.items():
+            v.set_option(key, val)
+        l2_, d2_ = search_np(v, bigd, k)
+        assert v.last_timing()["bucket_major"] == 1, opts
+        assert np.array_equal(l2_, lb_) and np.array_equal(d2_, db_), opts
+        for key, val in (("bm_boot", 1), ("bm_round", 6), ("bm_candidates", 0), ("bm_units", 0), ("bm_runs", 1),
+                         ("bm_queries_per_group", 0), ("bm_waves", 0)):
+            v.set_option(key, val)
+    v.set_option("timing", 0)
     # the streaming measurement form (bucket_skip = 0) returns the same results
     v.set_option("bucket_skip", 0)
     for n in (2, 32):
