@@ -88,6 +88,9 @@ def parse():
                     help="N = 1 default run: skip the in-process 1B x 16 B roofline / scale_base leg")
     ap.add_argument("--c5-rows", type=int, default=1_000_000_000, help="rows of that leg (rehearsals)")
     ap.add_argument("--c5-launches", type=int, default=12)
+    ap.add_argument("--c5-parity-queries", type=int, default=16,
+                    help="queries of that leg's 10k-query result checked against the CPU oracle over ALL its rows "
+                         "(0 = skip; keeps a uint16 host copy of the codes, 32 GB at 1B rows)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "replicas", "weak"],
                     help="N > 1: strong (default) = the same queries, rows (or queries) split over the GPUs; "
                          "replicas (alias weak) = every GPU its own nq queries on a replicated index, no collective")
@@ -241,6 +244,8 @@ def scan_kernel_name(info, tm, ti=False, no_skip=False):
     if ti:
         return "scan_%s_ti_kernel" % ("bytes" if info["layout"] == 0 else "bits")
     if info["layout"] == 0:
+        if tm.get("bucket_major"):
+            return "scan_bm_kernel<%d, 4, true>" % info["M"]
         if tm["early_abandon"] == 2:
             return "scan_bytes_inplace_kernel<%d, %d, %s>" % (info["M"], tm["queries_per_pass"],
                                                               "true" if no_skip else "false")
@@ -272,8 +277,10 @@ def c5_leg(args, dev, device_index, k):
     nq_full = 10_000
     queries = harness.sift_like(nq_full, D, stream=7, device=dev)
     t0 = time.time()
-    v, _, _, _ = build_index(bits, N, 0, N, dev, device_index, 1, 0, iters=8,
-                             gt_queries=None if args.no_recall else queries[:100].contiguous(), gt_k=k)
+    n_par = 0 if args.no_cpu else max(0, args.c5_parity_queries)
+    v, host_codes, cents, _ = build_index(bits, N, 0, N, dev, device_index, 1, 0, iters=8,
+                                          keep_host_rows=N if n_par else 0,
+                                          gt_queries=None if args.no_recall else queries[:100].contiguous(), gt_k=k)
     gt = build_index.ground_truth
     info = v.info()
     build_s = time.time() - t0
@@ -351,8 +358,38 @@ def c5_leg(args, dev, device_index, k):
         "pre_pass_ms": round(tm3["seed_ms"], 3), "merge_ms": round(tm3["merge_ms"], 3),
         "queries_per_pass": tm3["queries_per_pass"], "passes": tm3["passes"],
     }
+    scale_base["form"] = ("bucket-major rounds (vaq_scan_bm.hip): every bucket streamed once for all the queries that "
+                          "reach it" if tm3.get("bucket_major") else "one best-first workgroup per (query, slice)")
     assert bool(torch.equal(outf[0][:2], stream_labels) and torch.equal(outf[1][:2], stream_dists)), \
         "c5 leg: the 10k-query batch and the streaming pass disagree on the first two queries"
+    if n_par and host_codes is not None:
+        # the timed 10k-query result against the CPU oracle over ALL rows (a <= 32-query
+        # subset at full N): distances bit for bit, labels under the tie contract
+        from oracle import pyoracle as po
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from helpers import assert_topk_matches
+        po.build(ref=False)
+        threads = max(1, min(po.max_threads(), os.cpu_count() or 1, n_par))
+        qh = queries[:n_par].cpu().numpy()
+        t1 = time.perf_counter()
+        ol, od = po.search(qh, cents, host_codes, k, eig=v.mEigenVectors, nthreads=threads)
+        dt = time.perf_counter() - t1
+        gl, gd = outf[0][:n_par].cpu().numpy(), outf[1][:n_par].cpu().numpy()
+        Xp = po.project(qh, v.mEigenVectors)
+        boundary = 0
+        for q in range(n_par):
+            try:
+                assert_topk_matches(gl[q:q + 1], gd[q:q + 1], ol[q:q + 1], od[q:q + 1], None, what="c5 leg parity")
+            except AssertionError:  # (every distance of the database is only needed to adjudicate a boundary tie)
+                ad = po.all_dists(po.create_lut(Xp[q], cents, 8), host_codes)[None]
+                boundary += assert_topk_matches(gl[q:q + 1], gd[q:q + 1], ol[q:q + 1], od[q:q + 1], ad, what="c5 leg parity")
+                del ad
+        scale_base["parity"] = {"checked_queries": n_par, "rows": N, "distances_bit_exact": True,
+                                "boundary_tie_queries": boundary, "oracle_seconds": round(dt, 1), "oracle_threads": threads,
+                                "what": "queries 0..%d of the timed 10k-query result against oracle/vaq_oracle.c over "
+                                        "all %d encoded rows" % (n_par - 1, N)}
+        log(f"[c5 leg] {n_par} queries of the 10k-query result match the oracle over {N} rows ({dt:.1f}s, {threads} threads)")
+    del host_codes
     if gt is not None:
         lab = outf[0][:100].cpu().numpy()
         scale_base["recall"] = {

@@ -257,4 +257,35 @@ def test_c5_1b_rows(vaqlib, oracle):
     host = c["codes"].cpu().numpy().view(np.uint16)
     del c["codes"]
     torch.cuda.empty_cache()
-    check_oracle(oracle, c, host, base[0], base[1], 2, k, "c5 1B")
+    check_oracle(oracle, c, host, base[0], base[1], 8, k, "c5 1B")
+
+
+def test_c5_encoded_rows(vaqlib, oracle):
+    """C5's shape on ENCODED rows (clustered SIFT-shaped vectors through the product's encoder, bench.py's
+    recipe): 200M x 16 B, where a query reaches a few per cent of the buckets -- unlike uniform-random codes,
+    where nothing can be pruned.  512 queries through the bucket-major rounds (the library's choice), 8 of
+    them against the oracle over all rows, and the rounds against the one-workgroup-per-query form."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from vaq_amd import harness
+    N, k, nq = 200_000_000, 100, 512
+    dev = torch.device("cuda", 0)
+    v, host, cents, _ = bench.build_index([8] * 16, N, 0, N, dev, 0, 1, 0, iters=8, keep_host_rows=N)
+    queries = harness.sift_like(nq, 128, stream=7, device=dev)
+    v.set_option("timing", 1)
+    base = search_np(v, queries, k)
+    t = v.last_timing()
+    assert t["bucket_major"] == 1, t
+    check_sorted_unique(base[0], base[1], N, k)
+    v.set_option("bucket_major", 0)
+    l0, d0 = search_np(v, queries, k)
+    assert v.last_timing()["bucket_major"] == 0
+    assert np.array_equal(l0, base[0]) and np.array_equal(d0.view(np.uint32), base[1].view(np.uint32))
+    v.set_option("bucket_major", 1)
+    v.set_option("timing", 0)
+    c = dict(X=queries[:8].cpu().numpy(), eig=v.mEigenVectors, cents=cents, bits=[8] * 16)
+    v.close()
+    check_oracle(oracle, c, host, base[0], base[1], 8, k, "c5 encoded 200M")
