@@ -330,7 +330,16 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       effect when the codes are (re)set
  *   "bucket_skip"       1 (default); 0 visits every bucket -- for measuring the streaming
  *                       rate of the scan, results are the same                             */
-/*   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 128
+/*   "exact_ties"        0 (default): among rows of exactly equal distance the smaller label wins (above).
+ *                       1: the reference's own choice -- which of several rows tying at the k-th
+ *                       distance survive, and the order equal distances are returned in, come from
+ *                       its heap (VAQ.cpp:1750-1757, utils/Heap.hpp:115-169, 322-349).  The scan runs
+ *                       with k + 1; a query whose k + 1 smallest distances are distinct is unaffected,
+ *                       every other query is replayed through that heap over ALL rows in original
+ *                       order (one workgroup per such query: cheap at 1M rows, about a second per
+ *                       query at 1B).  HEAP / EA without TI, k < 1024; labels and distances are then
+ *                       identical to VAQ::search's, slot for slot.
+ *   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 128
  *                       queries in the call, the best-first pass is cut after each query's nearest
  *                       buckets and what is left in reach is scanned bucket by bucket: a bucket's
  *                       rows are streamed once for ALL the queries that still want it, four

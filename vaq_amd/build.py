@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "vaq_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "vaq_amd", "lib")
 LIB = os.path.join(LIBDIR, "libvaqhip.so")
-SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_scan_bm.hip", "vaq_ti.hip", "vaqhip_api.cpp", "vaqhip_multi.cpp"]
+SOURCES = ["vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_scan_bm.hip", "vaq_exact.hip", "vaq_ti.hip", "vaqhip_api.cpp", "vaqhip_multi.cpp"]
 KERNEL_HEADER = os.path.join(CSRC, "vaq_kernels.h")
 API_HEADER = os.path.join(ROOT, "include", "vaqhip.h")
 
@@ -27,7 +27,7 @@ def _deps(src: str):
     deps = [os.path.join(CSRC, src), KERNEL_HEADER]
     if src.endswith(".cpp"):
         deps.append(API_HEADER)
-    if src in ("vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_scan_bm.hip"):
+    if src in ("vaq_kernels.hip", "vaq_scan_bytes.hip", "vaq_scan_bits.hip", "vaq_scan_bf.hip", "vaq_scan_bm.hip", "vaq_exact.hip"):
         deps.append(SCAN_HEADER)
     if src in ("vaq_kernels.hip", "vaq_scan_bf.hip", "vaq_scan_bm.hip"):
         deps.append(SCAN_BF_HEADER)

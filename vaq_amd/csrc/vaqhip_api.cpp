@@ -126,6 +126,10 @@ struct vaqhip_index {
   DevBuf w_defer;  // [0] entries asked for, then DEFER_CAP records (best-first form, queries cut in two)
   // bucket-major second pass: plan arrays, per-bucket query lists, candidates, per-query words
   DevBuf w_bm_small, w_bm_mask, w_bm_qlist, w_bm_cand_d, w_bm_cand_id, w_bm_query, w_bm_thr64;
+  // option "exact_ties": original row -> bucketed row (built at the first such search after the codes change),
+  // the scan's k + 1 results, the replay list
+  DevBuf d_inv, w_ex_labels, w_ex_dist, w_ex_list;
+  bool inv_valid = false;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
   // serialised by `mu`, but `_device` entry points run on the caller's stream: the last enqueue
@@ -135,7 +139,7 @@ struct vaqhip_index {
   hipStream_t ws_stream = nullptr;
   bool ws_used = false;
   // options
-  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0, opt_sub_order = 1, opt_bm_sub = 1, opt_bm_boot = 1, opt_bm_round = 6;
+  int opt_qb = 0, opt_slices = 0, opt_timing = 0, opt_ea = 3, opt_nwaves = 0, opt_seed = 1, opt_hot = 16, opt_seed_frac = 64, opt_order = 0, opt_bucket_bits = 0, opt_no_skip = 0, opt_bf = 1, opt_group = 1, opt_defer = 0, opt_cost_order = 1, opt_bm = 1, opt_bm_cap = 0, opt_bm_units = 0, opt_bm_qb = 0, opt_bm_nwaves = 0, opt_sub_order = 1, opt_bm_sub = 1, opt_bm_boot = 1, opt_bm_round = 6, opt_exact = 0;
   // timing: a ring of 5-event sets, one per search since the last read
   static constexpr int EV_SETS = 256;
   std::vector<hipEvent_t> ev;   // EV_SETS * 6, created on first use
@@ -461,8 +465,8 @@ int ensure_events(vaqhip_index *ix) {
 }
 
 // core: device pointers in, device pointers out, enqueue only
-int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
-                         int32_t *d_labels, float *d_dist, hipStream_t st) {
+int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                int32_t *d_labels, float *d_dist, hipStream_t st) {
   if (ix->N < 0) return fail(VAQHIP_ESTATE, "search before codes were set");
   if (((ix->methods & VAQHIP_METHOD_TI) != 0) != (ix->ti_T > 0))
     return fail(VAQHIP_ESTATE, ix->ti_T > 0 ? "the rows are grouped by TI cluster: the method must include TI"
@@ -926,6 +930,42 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   return ws_release(ix, st);
 }
 
+// Option "exact_ties": the scan runs with k + 1; queries whose k + 1 smallest distances are distinct
+// have a unique answer and are copied out, the others are replayed through the reference's heap in
+// original row order (vaq_exact.hip).  One internal launch set (<= QUERY_CHUNK queries) at a time: the
+// replay reads that set's lookup tables.
+int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                         int32_t *d_labels, float *d_dist, hipStream_t st) {
+  const bool exact = ix->opt_exact && ix->ti_T == 0 && !ix->seq && nq > 0 && k > 0 && k < VAQHIP_MAX_K && ix->N >= 0 &&
+                     d_queries && d_labels && d_dist;
+  if (!exact) return search_core(ix, d_queries, nq, k, projected, d_labels, d_dist, st);
+  const int chunk = std::min(nq, QUERY_CHUNK);
+  HIP_TRY(ix->w_ex_labels.ensure((size_t)chunk * (k + 1) * sizeof(int32_t)));
+  HIP_TRY(ix->w_ex_dist.ensure((size_t)chunk * (k + 1) * sizeof(float)));
+  HIP_TRY(ix->w_ex_list.ensure((size_t)chunk * sizeof(int) + 16));
+  if (ix->N > 0 && !ix->inv_valid) {
+    HIP_TRY(ix->d_inv.ensure((size_t)ix->N * sizeof(uint32_t)));
+    HIP_TRY(vaq::launch_inverse_perm(ix->d_perm.as<uint32_t>(), ix->N, ix->d_inv.as<uint32_t>(), st));
+    ix->inv_valid = true;
+  }
+  for (int q0 = 0; q0 < nq; q0 += chunk) {
+    const int n = std::min(chunk, nq - q0);
+    int rc = search_core(ix, d_queries + (size_t)q0 * ix->D, n, k + 1, projected, ix->w_ex_labels.as<int32_t>(),
+                         ix->w_ex_dist.as<float>(), st);
+    if (rc) return rc;
+    rc = ws_acquire(ix, st);
+    if (rc) return rc;
+    HIP_TRY(vaq::launch_exact_ties(ix->d_codes.as<uint32_t>(), ix->layout, ix->M, ix->W, ix->d_sub.as<vaq::SubDesc>(),
+                                   ix->d_inv.as<uint32_t>(), ix->N, ix->w_lut.as<float>(), ix->lut_floats, n, k, ix->id_base,
+                                   ix->w_ex_labels.as<int32_t>(), ix->w_ex_dist.as<float>(), d_labels + (size_t)q0 * k,
+                                   d_dist + (size_t)q0 * k, reinterpret_cast<int *>(ix->w_ex_list.as<unsigned char>() + 16),
+                                   ix->w_ex_list.as<unsigned>(), st));
+    rc = ws_release(ix, st);
+    if (rc) return rc;
+  }
+  return VAQHIP_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1150,6 +1190,7 @@ static int build_rows(vaqhip_index *ix, const uint16_t *d_u16, int64_t N, hipStr
   ix->bucket_t = bt;
   ix->n_buckets = K0;
   ix->sub_fine = N > 0 ? fine : 0;
+  ix->inv_valid = false;
   return VAQHIP_OK;
 }
 
@@ -1239,6 +1280,7 @@ static int append_rows_bucketed(vaqhip_index *ix, const uint16_t *d_new, int64_t
     HIP_TRY(hipMemcpy(ix->d_bstart.p, ts.data(), (size_t)(K0 + 1) * sizeof(int), hipMemcpyHostToDevice));
   }
   ix->N = N;
+  ix->inv_valid = false;
   return VAQHIP_OK;
 }
 
@@ -1696,6 +1738,8 @@ int vaqhip_set_option(vaqhip_index *ix, const char *key, int64_t value) {
   } else if (k == "defer_units") {
     if (value < -1 || value > 1 << 20) return fail(VAQHIP_EINVAL, "defer_units must be -1 (automatic), 0 (off) or a number of work units");
     ix->opt_defer = (int)value;
+  } else if (k == "exact_ties") {
+    ix->opt_exact = value != 0;
   } else if (k == "bm_boot") {
     if (value < 0 || value > 2) return fail(VAQHIP_EINVAL, "bm_boot must be 0 (never), 1 (automatic) or 2 (always)");
     ix->opt_bm_boot = (int)value;
