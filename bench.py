@@ -723,6 +723,28 @@ def main():
                             "distances; a boundary tie (k-th == (k+1)-th distance) keeps the smallest labels "
                             "where the reference's choice depends on its heap (DESIGN.md 'Ties')",
             }
+            # option "exact_ties": the same batch with the reference's own choice among equal distances
+            # (its heap replayed for the queries that have ties): labels identical slot for slot
+            v.set_option("exact_ties", 1)
+            xl, xd = v.search_device(my_queries, k)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                v.search_device(my_queries, k, out=(xl, xd))
+            torch.cuda.synchronize()
+            x_ms = (time.perf_counter() - t1) / 3 * 1e3
+            v.set_option("exact_ties", 0)
+            xl_h, xd_h = xl[:chk].cpu().numpy(), xd[:chk].cpu().numpy()
+            assert np.array_equal(xd_h.view(np.uint32), cd[:chk].view(np.uint32)), "bench parity (exact_ties): distances differ"
+            differ = int((xl_h != cl[:chk]).any(axis=1).sum())
+            assert differ == 0, "bench parity (exact_ties): labels differ for %d queries" % differ
+            parity["exact_ties"] = {
+                "checked_queries": chk, "labels_identical_slot_for_slot": True, "boundary_tie_queries": 0,
+                "ms_per_step": round(x_ms, 4), "ms_per_step_default": round(ms_per_step, 4),
+                "note": "option exact_ties = 1: the scan runs with k + 1, queries whose k + 1 smallest distances are "
+                        "distinct are copied, the others replayed through the reference's heap in original row order "
+                        "(vaq_exact.hip); plain equality of labels against oracle/vaq_oracle.c",
+            }
         cpu["parity_checked_queries"] = parity["checked_queries"] if parity else 0
     v.close()
     del v

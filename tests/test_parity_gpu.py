@@ -476,6 +476,63 @@ def test_query_lut_sequential(vaqlib, oracle, ndim, seed):
                             what=f"queryLUT ndim={ndim} qb={qb} ea={ea}")
 
 
+@pytest.mark.parametrize("with_eig", [True, False], ids=["rotated", "identity"])
+def test_query_lut_checked_projection(vaqlib, oracle, with_eig):
+    """BitVecEngine::queryLUT projects with checking (BitVecEngine.hpp:53-71 called at :1226): a PCA
+    coordinate that comes out NaN or infinite becomes 0 before the tables are built.  One non-finite
+    component of the query makes EVERY coordinate of z * V non-finite (NaN * 0 = NaN), so such a
+    query is answered as the zero vector -- not with -1s, as VAQ::search (unchecked) answers."""
+    import vaq_amd
+    rng = np.random.default_rng(77)
+    ndim, N, nq, k = 12, 5000, 6, 20
+    bits = rng.integers(2, 9, ndim).tolist()
+    cent = np.zeros((256, ndim), np.float32)
+    for d, b in enumerate(bits):
+        cent[: 1 << b, d] = np.sort(rng.normal(size=1 << b) * 20).astype(np.float32)
+    codes = np.stack([rng.integers(0, 1 << b, N) for b in bits], 1).astype(np.uint16)
+    eig = None
+    if with_eig:
+        q, _ = np.linalg.qr(rng.normal(size=(ndim, ndim)))
+        eig = q.astype(np.float32)
+    X = (rng.normal(size=(nq, ndim)) * 20).astype(np.float32)
+    X[1, 3] = np.nan
+    X[2, 0] = np.inf
+    X[4, 5] = -np.inf
+    X[4, 6] = np.nan
+    # restatement of :53-71 on top of the oracle's fixed-order product (z * I for the identity)
+    with np.errstate(invalid="ignore", over="ignore"):
+        Xp = oracle.project(X, eig if with_eig else np.eye(ndim, dtype=np.float32))
+    assert not np.isfinite(Xp[[1, 2, 4]]).any() and np.isfinite(Xp[[0, 3, 5]]).all()
+    Xc = np.where(np.isfinite(Xp), Xp, np.float32(0)).astype(np.float32)
+    v = vaq_amd.VaqHip(sequential_sum=True)
+    v.mBitsAlloc = bits
+    v.mCentroidsPerSubs = [np.ascontiguousarray(cent[: 1 << b, d:d + 1]) for d, b in enumerate(bits)]
+    v.mEigenVectors = eig
+    v.mCodebook = codes
+    o_lab = np.empty((nq, k), np.int32)
+    o_dis = np.empty((nq, k), np.float32)
+    ad = np.empty((nq, N), np.float32)
+    for i in range(nq):
+        o_lab[i], o_dis[i] = oracle.query_lut_1d(Xc[i], bits, cent, codes, k)
+        lut = [np.float32((Xc[i, d] - cent[: 1 << bits[d], d]) ** 2) for d in range(ndim)]
+        acc = lut[0][codes[:, 0]].astype(np.float32)
+        for d in range(1, ndim):
+            acc = (acc + lut[d][codes[:, d]]).astype(np.float32)
+        ad[i] = acc
+    a = v.search(X, k)
+    lab, dis = a.labels.reshape(nq, k), a.distances.reshape(nq, k)
+    assert (lab >= 0).all()  # every query is answered
+    assert_topk_matches(lab, dis, o_lab, o_dis, ad, what="queryLUT, checked projection")
+    # VAQ::search does not check (VAQ.hpp:198-201): a NaN query has no row with heap_top > dist
+    w = vaq_amd.VaqHip()
+    w.mBitsAlloc = [4] * ndim
+    w.mCentroidsPerSubs = [np.ascontiguousarray(cent[:16, d:d + 1]) for d in range(ndim)]
+    w.mEigenVectors = eig
+    w.mCodebook = (codes & 15).astype(np.uint16)
+    b = w.search(X, k)
+    assert (b.labels.reshape(nq, k)[1] == -1).all()
+
+
 def test_lock_contention_stress(vaqlib, oracle):
     """Worst case for the workgroup admission lock: every row has the same code, so every
     row ties with the threshold distance and only the label order decides; 16 waves per

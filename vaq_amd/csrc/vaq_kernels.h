@@ -123,8 +123,9 @@ struct ScanParams {
   int *part_id;
 };
 
+// checked != 0: non-finite coordinates of the product become 0 (BitVecEngine.hpp:53-71); E == nullptr = identity
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
-                          hipStream_t st);
+                          hipStream_t st, int checked = 0);
 // cent_t: the codebooks dimension-major (entry j * ncent + c of subspace s at cent_off)
 // min_ncent: the smallest codebook (subspaces of < 8 centroids take the reference's scalar branch)
 hipError_t launch_lut_build(const float *qproj, int nq, int D, int M, int L,

@@ -27,27 +27,42 @@ namespace vaq {
 // One workgroup per row; thread c owns output column c; fmaf chain over the
 // inner index ascending (the reference leaves the order to Eigen's GEMM).
 // ---------------------------------------------------------------------------
+// checked: BitVecEngine::ProjectOnEigenVectors(Z, withChecking = true) (BitVecEngine.hpp:53-71, called
+// by queryLUT at :1226): a coordinate that comes out NaN or infinite is replaced by 0.  E == nullptr
+// stands for the identity matrix: the product z * I is then NaN in EVERY column as soon as one
+// component of z is not finite (NaN * 0 and inf * 0 are NaN), i.e. the whole row becomes 0.
 __global__ void project_kernel(const float *__restrict__ X, int D,
-                               const float *__restrict__ E, float *__restrict__ out) {
+                               const float *__restrict__ E, float *__restrict__ out, int checked) {
   extern __shared__ float xs[];
+  __shared__ int bad;
   const int64_t r = blockIdx.x;
+  if (threadIdx.x == 0) bad = 0;
   for (int j = threadIdx.x; j < D; j += blockDim.x) xs[j] = X[r * D + j];
   __syncthreads();
+  if (!E) {
+    for (int j = threadIdx.x; j < D; j += blockDim.x)
+      if (!(fabsf(xs[j]) <= FLT_MAX)) bad = 1;
+    __syncthreads();
+    const bool zero = checked && bad;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[r * D + c] = zero ? 0.0f : xs[c];
+    return;
+  }
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
     float acc = 0.0f;
     for (int j = 0; j < D; j++) acc = __builtin_fmaf(xs[j], E[(size_t)j * D + c], acc);
+    if (checked && !(fabsf(acc) <= FLT_MAX)) acc = 0.0f;
     out[r * D + c] = acc;
   }
 }
 
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
-                          hipStream_t st) {
+                          hipStream_t st, int checked) {
   if (n == 0) return hipSuccess;
   // (one workgroup per row: batching 8 rows per workgroup, as the LUT build does with queries,
   //  was measured slower here -- 0.044 vs 0.030 ms for 10 k rows: too few workgroups to fill the chip)
   int threads = D < 256 ? ((D + 63) / 64) * 64 : 256;
   hipLaunchKernelGGL(project_kernel, dim3((unsigned)n), dim3(threads), D * sizeof(float), st, X, D,
-                     E, out);
+                     E, out, checked);
   return hipGetLastError();
 }
 

@@ -498,7 +498,9 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
     if (rc) return rc;
   }
   const int chunk = std::min(nq, QUERY_CHUNK);
-  const bool do_project = !projected && ix->has_eig;
+  // (BitVecEngine::queryLUT projects with checking, BitVecEngine.hpp:1226: non-finite coordinates -> 0,
+  //  which needs a pass over the queries even without a rotation)
+  const bool do_project = !projected && (ix->has_eig || ix->seq);
   if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
   HIP_TRY(ix->w_lut.ensure((size_t)chunk * ix->lut_floats * sizeof(float)));
   const int nslots = std::max(pl.n_slices, pl.seed_slices);
@@ -552,7 +554,8 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
     const float *qp = dq;
     if (timing) HIP_TRY(hipEventRecord(ev[0], st));
     if (do_project) {
-      HIP_TRY(vaq::launch_project(dq, n, ix->D, ix->d_eig.as<float>(), ix->w_qproj.as<float>(), st));
+      HIP_TRY(vaq::launch_project(dq, n, ix->D, ix->has_eig ? ix->d_eig.as<float>() : nullptr, ix->w_qproj.as<float>(), st,
+                                  ix->seq ? 1 : 0));
       qp = ix->w_qproj.as<float>();
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], st));
@@ -1496,7 +1499,9 @@ int vaqhip_merge_topk_strided_device(int device_id, const float *d_dist_lists,
 // core of vaqhip_encode*: caller holds ix->mu and has the device current
 static int encode_device_locked(vaqhip_index *ix, const float *d_X, int64_t n, int projected, uint16_t *d_codes,
                                 hipStream_t st) {
-  const bool do_project = !projected && ix->has_eig;
+  // (BitVecEngine::queryLUT projects with checking, BitVecEngine.hpp:1226: non-finite coordinates -> 0,
+  //  which needs a pass over the queries even without a rotation)
+  const bool do_project = !projected && (ix->has_eig || ix->seq);
   const int64_t chunk = std::min<int64_t>(n, 1 << 20);
   if (do_project) HIP_TRY(ix->w_qproj.ensure((size_t)chunk * ix->D * sizeof(float)));
   {
