@@ -87,7 +87,10 @@ int vaqhip_index_create(vaqhip_index **out, int D, int M, const int *bits,
  * quantiser per PCA dimension (D == M, sub-vector length 1), LUT column stride 256, and
  * dist = ((l_0 + l_1) + l_2) + ... summed column by column (:1296-1300) instead of in
  * groups of four; M need not be a multiple of 4.  centroids[s] is then column s of the
- * engine's centroidsMat (1 << bits[s] values). */
+ * engine's centroidsMat (1 << bits[s] values).  Queries are projected WITH CHECKING, as queryLUT
+ * does (:1226 -> :53-71): a PCA coordinate that comes out NaN or infinite becomes 0 (one non-finite
+ * component makes every coordinate of z * V non-finite, so such a query is answered as the zero
+ * vector); VAQ::search's projection (VAQ.hpp:198-201) does not check and is left as it is. */
 #define VAQHIP_SUM_SEQUENTIAL 0x1u
 int vaqhip_index_create_ex(vaqhip_index **out, int D, int M, const int *bits,
                            const float *const *centroids_rowmajor,
@@ -233,13 +236,22 @@ int vaqhip_multi_create(vaqhip_multi **out, int D, int M, const int *bits,
                         const float *const *centroids_rowmajor, const float *eigvec_real_rowmajor,
                         int n_devices, const int *device_ids, unsigned flags);
 void vaqhip_multi_destroy(vaqhip_multi *mx);
-/* mCodebook for the whole database (host pointer); sharded contiguously across the devices */
+/* mCodebook for the whole database (host pointer); sharded contiguously across the devices, every
+ * shard uploaded, sorted and packed by its own host thread at the same time */
 int vaqhip_multi_set_codes_u16(vaqhip_multi *mx, const uint16_t *codes_rowmajor, int64_t N, int64_t id_base);
-/* append: the new rows continue the numbering, so they extend the last shard */
+/* append: the new rows continue the numbering, so they extend the LAST shard -- repeated appends pile
+ * rows (memory and scan time) on one device; vaqhip_multi_get_info's shard_rows shows the skew, and
+ * vaqhip_multi_set_codes_u16 with the whole matrix re-balances */
 int vaqhip_multi_add_codes_u16(vaqhip_multi *mx, const uint16_t *codes_rowmajor, int64_t n_new);
 /* VAQ::search on every shard + exchange + merge; host pointers, synchronous */
 int vaqhip_multi_search(vaqhip_multi *mx, const float *queries_rowmajor, int nq, int k, int projected,
                         int32_t *labels, float *distances);
+/* The same with device pointers, enqueue only: d_queries (nq x D) and the outputs live on device_ids[0];
+ * the call returns once every shard's work is enqueued -- each shard copies the queries over the fabric
+ * (hipMemcpyPeerAsync, no host staging), `stream` (a stream of device_ids[0]) is made to wait for the
+ * merged result, the host is not.  Like the single-index "_device" entry points it never synchronises. */
+int vaqhip_multi_search_device(vaqhip_multi *mx, const float *d_queries, int nq, int k, int projected,
+                               int32_t *d_labels, float *d_distances, void *stream);
 /* forwarded to every shard (each shard regroups its own rows under the same TI centres) */
 int vaqhip_multi_set_ti_clusters(vaqhip_multi *mx, const float *clusters_rowmajor, int T, int seg_num);
 int vaqhip_multi_set_method(vaqhip_multi *mx, unsigned methods, float visit);

@@ -119,3 +119,23 @@ def test_member_identity_tokens():
     assert not _same(r, b)
     lst = [1, 2, 3]
     assert _same(_wref(lst), lst)
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_job_pool_under_sanitizers(tmp_path, san):
+    """The host-side worker protocol of the multi-device index (vaq_amd/csrc/job_pool.h: persistent
+    threads, phases, the exchange only after every shard succeeded) on the CPU build under
+    ThreadSanitizer and AddressSanitizer: G = 2..8 workers, concurrent callers, failing shards."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++")
+    assert cxx
+    exe = str(tmp_path / f"job_pool_{san}")
+    subprocess.check_call([cxx, "-std=c++17", "-O1", "-g", f"-fsanitize={san}", "-fno-omit-frame-pointer", "-pthread",
+                           "-I" + os.path.join(root, "vaq_amd", "csrc"), os.path.join(root, "tests", "cpp", "job_pool_test.cpp"),
+                           "-o", exe])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=1")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "job_pool_test: ok" in out.stdout

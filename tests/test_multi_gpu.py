@@ -90,3 +90,50 @@ def test_multi_append_ti_and_errors(vaqlib, oracle):
     with pytest.raises(vaq_amd.VaqHipError):
         VaqHipMulti([], c["bits"], c["cents"], c["eig"])
     m.close()
+
+
+def test_a_failing_shard_does_not_hang_the_others(vaqlib):
+    """One shard of four refuses the search (its method is set to TI without clusters): the call
+    returns that shard's error, NO exchange step was enqueued for anybody (the collective is only
+    issued after every shard succeeded: vaqhip_multi.cpp, multi_search_common), the index answers
+    again once the shard is repaired, and destroy returns."""
+    import ctypes as C
+    from vaq_amd import _lib
+    from vaq_amd.index import VaqHipMulti
+    c = make_case(4300, 128, [8] * 8, 120_000, 11)
+    ref = single(c).search(c["X"], 10)
+    m = VaqHipMulti([0, 0, 0, 0], c["bits"], c["cents"], c["eig"])
+    m.set_codes(c["codes"])
+    L = _lib.load()
+    L.vaqhip_index_set_method.argtypes = [C.c_void_p, C.c_uint, C.c_float]
+    L.vaqhip_multi_shard.restype = C.c_void_p
+    bad = C.c_void_p(m.shard(2))
+    assert L.vaqhip_index_set_method(bad, 0x04 | 0x02, 1.0) == 0   # TI | EA, but no clusters were set
+    for _ in range(3):
+        with pytest.raises(_lib.VaqHipError) as e:
+            m.search(c["X"], 10)
+        assert "shard 2" in str(e.value)
+    assert L.vaqhip_index_set_method(bad, 0x80, 1.0) == 0          # HEAP again
+    a = m.search(c["X"], 10)
+    assert np.array_equal(a.labels, ref.labels) and np.array_equal(a.distances.view(np.uint32), ref.distances.view(np.uint32))
+    m.close()  # (joins the workers, synchronises and frees every shard: must return)
+
+
+def test_multi_search_device_entry(vaqlib):
+    """vaqhip_multi_search_device: queries and results stay on the device, the call only enqueues;
+    several searches back to back on one stream, then one synchronisation."""
+    import torch
+    from vaq_amd.index import VaqHipMulti
+    c = make_case(4400, 128, [8] * 16, 200_000, 33, dup_frac=0.02)
+    ref = single(c)
+    m = VaqHipMulti([0, 0, 0], c["bits"], c["cents"], c["eig"])
+    m.set_codes(c["codes"])
+    outs = []
+    for n, k in ((33, 100), (5, 10), (33, 100), (17, 1)):
+        q = torch.from_numpy(c["X"][:n]).cuda()
+        outs.append((n, k, m.search_device(q, k)))
+    torch.cuda.synchronize()
+    for n, k, (l, d) in outs:
+        r = ref.search(c["X"][:n], k)
+        assert np.array_equal(l.cpu().numpy().ravel(), r.labels) and np.array_equal(d.cpu().numpy().ravel().view(np.uint32), r.distances.view(np.uint32))
+    m.close()

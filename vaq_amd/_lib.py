@@ -23,7 +23,7 @@ SYMBOLS = [
     "vaqhip_index_info", "vaqhip_set_option", "vaqhip_last_timing", "vaqhip_last_error",
     "vaqhip_version", "vaqhip_device_count",
     "vaqhip_multi_create", "vaqhip_multi_destroy", "vaqhip_multi_set_codes_u16", "vaqhip_multi_add_codes_u16",
-    "vaqhip_multi_search", "vaqhip_multi_set_ti_clusters", "vaqhip_multi_set_method", "vaqhip_multi_set_option",
+    "vaqhip_multi_search", "vaqhip_multi_search_device", "vaqhip_multi_set_ti_clusters", "vaqhip_multi_set_method", "vaqhip_multi_set_option",
     "vaqhip_multi_get_info", "vaqhip_multi_shard", "vaqhip_multi_last_error",
 ]
 MAX_DEVICES = 16
@@ -126,6 +126,7 @@ def load():
     L.vaqhip_multi_set_codes_u16.argtypes = [vp, vp, i64, i64]
     L.vaqhip_multi_add_codes_u16.argtypes = [vp, vp, i64]
     L.vaqhip_multi_search.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.vaqhip_multi_search_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.vaqhip_multi_set_ti_clusters.argtypes = [vp, vp, i32, i32]
     L.vaqhip_multi_set_method.argtypes = [vp, C.c_uint, C.c_float]
     L.vaqhip_multi_set_option.argtypes = [vp, C.c_char_p, i64]

@@ -31,6 +31,8 @@
 #include <thread>
 #include <vector>
 
+#include "job_pool.h"
+
 namespace {
 
 int mfail(int code, const char *fmt, ...);
@@ -96,10 +98,7 @@ struct Shard {
   int32_t *d_gathered = nullptr;  // [G][2][nq][k] (every device under RCCL; shard 0 with copies)
   size_t cap_q = 0, cap_p = 0, cap_g = 0;
   ncclComm_t comm = nullptr;
-  // worker thread
-  std::thread th;
-  int rc = 0;
-  std::string err;
+  std::string err;  // what the shard's last phase failed with
 };
 
 } // namespace
@@ -111,14 +110,16 @@ struct vaqhip_multi {
   int exchange = EX_AUTO;
   bool comms_ready = false;
   int64_t N = 0, id_base = 0;
-  // one search at a time; workers run a job and report back
-  std::mutex mu, job_mu;
-  std::condition_variable job_cv, done_cv;
-  uint64_t job_seq = 0;
-  int job_pending = 0;
-  bool quit = false;
-  // the current job
-  const float *queries = nullptr;
+  // one call at a time (mu); every phase of it runs on the shards' worker threads (job_pool.h), and the
+  // caller only goes on to the next phase -- the collective -- when every shard has succeeded
+  mutable std::mutex mu;
+  vaq::JobPool pool;
+  // the current search
+  const float *queries = nullptr;      // host pointer, or
+  const float *d_queries0 = nullptr;   // device pointer on shard 0's device (vaqhip_multi_search_device)
+  hipEvent_t user_ready = nullptr;     //   recorded on the caller's stream: the queries are there
+  hipEvent_t consumed = nullptr;       // shard 0 has read every shard's packed result (copies) / merged
+  hipEvent_t finished = nullptr;       // the result is in the caller's device buffers
   int nq = 0, k = 0, projected = 0, use_rccl = 0;
   int32_t *d_out_labels = nullptr;
   float *d_out_dist = nullptr;
@@ -180,9 +181,17 @@ int run_shard(vaqhip_multi *mx, int g) {
       mx->cap_out = 2 * plane * 4;
     }
     mx->d_out_dist = reinterpret_cast<float *>(mx->d_out_labels + plane);
-    MHIP(hipEventRecord(mx->ev[0], s.stream));
   }
-  MHIP(hipMemcpyAsync(s.d_queries, mx->queries, (size_t)nq * mx->D * 4, hipMemcpyHostToDevice, s.stream));
+  // (the previous search's exchange has read this shard's packed result: never recorded = no wait)
+  MHIP(hipStreamWaitEvent(s.stream, mx->consumed, 0));
+  if (g == 0) MHIP(hipEventRecord(mx->ev[0], s.stream));
+  if (mx->d_queries0) {
+    // device entry: the queries sit on shard 0's device; every shard takes its copy over the fabric
+    MHIP(hipStreamWaitEvent(s.stream, mx->user_ready, 0));
+    MHIP(hipMemcpyPeerAsync(s.d_queries, s.device, mx->d_queries0, mx->sh[0].device, (size_t)nq * mx->D * 4, s.stream));
+  } else {
+    MHIP(hipMemcpyAsync(s.d_queries, mx->queries, (size_t)nq * mx->D * 4, hipMemcpyHostToDevice, s.stream));
+  }
   int32_t *labels = G == 1 ? mx->d_out_labels : s.d_packed;
   float *dist = G == 1 ? mx->d_out_dist : reinterpret_cast<float *>(s.d_packed + plane);
   const int rc = vaqhip_search_device(s.ix, s.d_queries, nq, k, mx->projected, labels, dist, s.stream);
@@ -191,21 +200,34 @@ int run_shard(vaqhip_multi *mx, int g) {
     return rc;
   }
   if (g == 0) MHIP(hipEventRecord(mx->ev[1], s.stream));
-  if (G > 1 && mx->use_rccl) {
-    // the exchange step: one collective, nq * k * 8 bytes per rank
-    const ncclResult_t nr = g_rccl.AllGather(s.d_packed, s.d_gathered, 2 * plane, NCCL_INT32, s.comm, s.stream);
-    if (nr != 0) {
-      s.err = std::string("ncclAllGather: ") + g_rccl.GetErrorString(nr);
-      return VAQHIP_EHIP;
-    }
-  }
   MHIP(hipEventRecord(s.done, s.stream));
+  return 0;
+}
+
+// The exchange step, issued by the CALLING thread once every shard's search is enqueued without error:
+// one ncclAllGather per device inside a group (nq * k * 8 bytes per rank over xGMI).  A shard that
+// failed has returned before this point and no collective was enqueued anywhere, so nothing can be
+// left waiting for a peer that never arrives.
+int exchange_rccl(vaqhip_multi *mx) {
+  const size_t plane = (size_t)mx->nq * mx->k;
+  ncclResult_t nr = g_rccl.GroupStart();
+  if (nr != 0) return mfail(VAQHIP_EHIP, "ncclGroupStart: %s", g_rccl.GetErrorString(nr));
+  ncclResult_t first = 0;
+  for (int g = 0; g < mx->G; g++) {
+    Shard &s = mx->sh[g];
+    if (hipSetDevice(s.device) != hipSuccess) { first = first ? first : -1; continue; }
+    nr = g_rccl.AllGather(s.d_packed, s.d_gathered, 2 * plane, NCCL_INT32, s.comm, s.stream);
+    if (nr != 0 && !first) first = nr;
+  }
+  nr = g_rccl.GroupEnd();
+  if (first != 0) return mfail(VAQHIP_EHIP, "ncclAllGather: %s", first > 0 ? g_rccl.GetErrorString(first) : "hipSetDevice");
+  if (nr != 0) return mfail(VAQHIP_EHIP, "ncclGroupEnd: %s", g_rccl.GetErrorString(nr));
   return 0;
 }
 
 // after every shard has enqueued its part: gather by copies when RCCL is not in play, merge on
 // shard 0's device, bring the result to the host
-int finish_on_shard0(vaqhip_multi *mx, int32_t *labels, float *distances) {
+int finish_on_shard0(vaqhip_multi *mx, int32_t *labels, float *distances, hipStream_t user) {
   Shard &s = mx->sh[0];
   const int G = mx->G, nq = mx->nq, k = mx->k;
   const size_t plane = (size_t)nq * k;
@@ -230,6 +252,16 @@ int finish_on_shard0(vaqhip_multi *mx, int32_t *labels, float *distances) {
     MHIP(hipEventRecord(mx->ev[2], s.stream));
   }
   MHIP(hipEventRecord(mx->ev[3], s.stream));
+  MHIP(hipEventRecord(mx->consumed, s.stream));
+  if (mx->d_queries0) {
+    // device entry: results into the caller's buffers on shard 0's device; the caller's stream waits
+    // for them, the host does not
+    MHIP(hipMemcpyAsync(labels, mx->d_out_labels, plane * 4, hipMemcpyDeviceToDevice, s.stream));
+    MHIP(hipMemcpyAsync(distances, mx->d_out_dist, plane * 4, hipMemcpyDeviceToDevice, s.stream));
+    MHIP(hipEventRecord(mx->finished, s.stream));
+    MHIP(hipStreamWaitEvent(user, mx->finished, 0));
+    return 0;
+  }
   MHIP(hipMemcpyAsync(labels, mx->d_out_labels, plane * 4, hipMemcpyDeviceToHost, s.stream));
   MHIP(hipMemcpyAsync(distances, mx->d_out_dist, plane * 4, hipMemcpyDeviceToHost, s.stream));
   MHIP(hipStreamSynchronize(s.stream));
@@ -244,25 +276,6 @@ int finish_on_shard0(vaqhip_multi *mx, int32_t *labels, float *distances) {
   mx->last.last_exchange_ms = ms[1];
   mx->last.last_merge_ms = ms[2];
   return 0;
-}
-
-void worker(vaqhip_multi *mx, int g) {
-  uint64_t seen = 0;
-  for (;;) {
-    {
-      std::unique_lock<std::mutex> lk(mx->job_mu);
-      mx->job_cv.wait(lk, [&] { return mx->quit || mx->job_seq != seen; });
-      if (mx->quit) return;
-      seen = mx->job_seq;
-    }
-    Shard &s = mx->sh[g];
-    s.err.clear();
-    s.rc = run_shard(mx, g);
-    {
-      std::lock_guard<std::mutex> lk(mx->job_mu);
-      if (--mx->job_pending == 0) mx->done_cv.notify_all();
-    }
-  }
 }
 
 int ensure_comms(vaqhip_multi *mx) {
@@ -311,27 +324,25 @@ int vaqhip_multi_create(vaqhip_multi **out, int D, int M, const int *bits, const
     }
     bool ok = hipSetDevice(s.device) == hipSuccess && hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
-    if (g == 0)
+    if (g == 0) {
       for (auto &e : mx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&mx->user_ready, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&mx->consumed, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&mx->finished, hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
       vaqhip_multi_destroy(mx);
       return mfail(VAQHIP_EHIP, "stream / event creation on device %d failed", s.device);
     }
   }
-  for (int g = 0; g < n_devices; g++) mx->sh[g].th = std::thread(worker, mx, g);
+  mx->pool.start(n_devices);
   *out = mx;
   return VAQHIP_OK;
 }
 
 void vaqhip_multi_destroy(vaqhip_multi *mx) {
   if (!mx) return;
-  {
-    std::lock_guard<std::mutex> lk(mx->job_mu);
-    mx->quit = true;
-  }
-  mx->job_cv.notify_all();
-  for (auto &s : mx->sh)
-    if (s.th.joinable()) s.th.join();
+  mx->pool.stop();
   for (auto &s : mx->sh) {
     (void)hipSetDevice(s.device);
     if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -347,6 +358,8 @@ void vaqhip_multi_destroy(vaqhip_multi *mx) {
   if (mx->d_out_labels) (void)hipFree(mx->d_out_labels);
   for (auto &e : mx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {mx->user_ready, mx->consumed, mx->finished})
+    if (e) (void)hipEventDestroy(e);
   delete mx;
 }
 
@@ -359,12 +372,18 @@ int vaqhip_multi_set_codes_u16(vaqhip_multi *mx, const uint16_t *codes, int64_t 
     Shard &s = mx->sh[g];
     s.lo = std::min<int64_t>(N, (int64_t)g * per);
     s.n = std::min<int64_t>(N, (int64_t)(g + 1) * per) - s.lo;
-    const int rc = vaqhip_index_set_codes_u16(s.ix, codes + s.lo * mx->M, s.n, id_base + s.lo);
-    if (rc) {
-      g_merr = vaqhip_last_error();
-      return rc;
-    }
   }
+  // every shard uploads, sorts and packs its rows on its own device, all of them at once
+  const int rc = mx->pool.run([&](int g) -> int {
+    Shard &s = mx->sh[g];
+    s.err.clear();
+    const int r = vaqhip_index_set_codes_u16(s.ix, codes + s.lo * mx->M, s.n, id_base + s.lo);
+    if (r) s.err = vaqhip_last_error();
+    return r;
+  });
+  if (rc)
+    for (int g = 0; g < mx->G; g++)
+      if (mx->pool.rc(g)) return mfail(mx->pool.rc(g), "shard %d (device %d): %s", g, mx->sh[g].device, mx->sh[g].err.c_str());
   mx->N = N;
   mx->id_base = id_base;
   return VAQHIP_OK;
@@ -433,12 +452,12 @@ int vaqhip_multi_set_option(vaqhip_multi *mx, const char *key, int64_t value) {
   return VAQHIP_OK;
 }
 
-int vaqhip_multi_search(vaqhip_multi *mx, const float *queries, int nq, int k, int projected, int32_t *labels,
-                        float *distances) {
+static int multi_search_common(vaqhip_multi *mx, const float *queries, const float *d_queries0, hipStream_t user, int nq, int k,
+                               int projected, int32_t *labels, float *distances) {
   if (!mx) return mfail(VAQHIP_EINVAL, "multi index is null");
   if (nq < 0 || k <= 0) return mfail(VAQHIP_EINVAL, "nq=%d k=%d", nq, k);
   if (nq == 0) return VAQHIP_OK;
-  if (!queries || !labels || !distances) return mfail(VAQHIP_EINVAL, "null pointer");
+  if ((!queries && !d_queries0) || !labels || !distances) return mfail(VAQHIP_EINVAL, "null pointer");
   std::lock_guard<std::mutex> lk(mx->mu);
   // RCCL when the GPUs are distinct and there is something to exchange (or when asked for by
   // option, which also exercises it on one device); device-to-device copies otherwise
@@ -450,21 +469,31 @@ int vaqhip_multi_search(vaqhip_multi *mx, const float *queries, int nq, int k, i
   // a one-shard index asked to use RCCL still goes through the collective (G == 1 skips packing)
   mx->use_rccl = rccl && mx->G > 1;
   mx->queries = queries;
+  mx->d_queries0 = d_queries0;
   mx->nq = nq;
   mx->k = k;
   mx->projected = projected;
-  {
-    std::lock_guard<std::mutex> jl(mx->job_mu);
-    mx->job_pending = mx->G;
-    mx->job_seq++;
+  if (d_queries0) {
+    if (hipSetDevice(mx->sh[0].device) != hipSuccess || hipEventRecord(mx->user_ready, user) != hipSuccess)
+      return mfail(VAQHIP_EHIP, "recording the caller's stream");
   }
-  mx->job_cv.notify_all();
-  {
-    std::unique_lock<std::mutex> jl(mx->job_mu);
-    mx->done_cv.wait(jl, [&] { return mx->job_pending == 0; });
+  // phase 1: every shard uploads (or copies) the queries and enqueues its search
+  const int rc1 = mx->pool.run([&](int g) -> int {
+    mx->sh[g].err.clear();
+    return run_shard(mx, g);
+  });
+  if (rc1) {
+    // Nothing of the exchange has been enqueued: the shards that did succeed have complete, ordinary
+    // work on their streams, and the index stays usable (and destroyable).
+    for (int g = 0; g < mx->G; g++)
+      if (mx->pool.rc(g))
+        return mfail(mx->pool.rc(g), "shard %d (device %d): %s", g, mx->sh[g].device, mx->sh[g].err.c_str());
   }
-  for (int g = 0; g < mx->G; g++)
-    if (mx->sh[g].rc) return mfail(mx->sh[g].rc, "shard %d (device %d): %s", g, mx->sh[g].device, mx->sh[g].err.c_str());
+  // phase 2: the exchange, only now that every shard is known to take part
+  if (mx->use_rccl) {
+    const int rc = exchange_rccl(mx);
+    if (rc) return rc;
+  }
   if (rccl && mx->G == 1) {
     // one rank: the collective degenerates to a copy; run it anyway so that a one-GPU box
     // proves the RCCL binding (communicator, stream, datatype) end to end
@@ -479,14 +508,26 @@ int vaqhip_multi_search(vaqhip_multi *mx, const float *queries, int nq, int k, i
       return mfail(VAQHIP_EHIP, "copy back from the gathered buffer");
   }
   Shard &s0 = mx->sh[0];
-  const int rc = finish_on_shard0(mx, labels, distances);
+  const int rc = finish_on_shard0(mx, labels, distances, user);
   if (rc) return mfail(rc, "exchange / merge on device %d: %s", s0.device, s0.err.c_str());
   mx->last.exchange = rccl ? EX_RCCL : (mx->G == 1 ? 0 : EX_COPIES);
   return VAQHIP_OK;
 }
 
+int vaqhip_multi_search(vaqhip_multi *mx, const float *queries, int nq, int k, int projected, int32_t *labels,
+                        float *distances) {
+  return multi_search_common(mx, queries, nullptr, nullptr, nq, k, projected, labels, distances);
+}
+
+int vaqhip_multi_search_device(vaqhip_multi *mx, const float *d_queries, int nq, int k, int projected, int32_t *d_labels,
+                               float *d_distances, void *stream) {
+  return multi_search_common(mx, nullptr, d_queries, static_cast<hipStream_t>(stream), nq, k, projected, d_labels,
+                             d_distances);
+}
+
 int vaqhip_multi_get_info(const vaqhip_multi *mx, vaqhip_multi_info *out) {
   if (!mx || !out) return mfail(VAQHIP_EINVAL, "null pointer");
+  std::lock_guard<std::mutex> lk(mx->mu);  // (a search in flight writes these)
   *out = mx->last;
   out->n_devices = mx->G;
   out->N = mx->N;

@@ -542,6 +542,27 @@ class VaqHipMulti:
                                                          _ptr(ret.labels), _ptr(ret.distances)))
         return ret
 
+    def search_device(self, d_queries, k: int, projected: bool = False, out=None):
+        """vaqhip_multi_search_device: torch CUDA tensors on the FIRST device of the list in and out,
+        enqueued behind torch's current stream of that device; nothing is synchronised."""
+        import torch
+        q = d_queries.contiguous()
+        assert q.is_cuda and q.dtype == torch.float32 and q.shape[1] == self.D
+        nq = q.shape[0]
+        if out is None:
+            out = (torch.empty((nq, k), dtype=torch.int32, device=q.device),
+                   torch.empty((nq, k), dtype=torch.float32, device=q.device))
+        labels, dists = out
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check_multi(_lib.load().vaqhip_multi_search_device(
+            self._h, C.c_void_p(q.data_ptr()), nq, k, 1 if projected else 0, C.c_void_p(labels.data_ptr()),
+            C.c_void_p(dists.data_ptr()), C.c_void_p(stream)))
+        return labels, dists
+
+    def shard(self, g: int):
+        """vaqhip_multi_shard: the raw handle of shard g's single-device index (owned by the multi index)."""
+        return _lib.load().vaqhip_multi_shard(self._h, g)
+
     def info(self) -> dict:
         inf = _lib.MultiInfo()
         _lib.check_multi(_lib.load().vaqhip_multi_get_info(self._h, C.byref(inf)))
