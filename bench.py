@@ -258,11 +258,21 @@ def scan_kernel_name(info, tm, ti=False, no_skip=False):
                                                        tm["early_abandon"])
 
 
+PROFILE_ROUND = "r03"
+
+
 def load_profile_json(name):
+    """Counter figures collected by tools/profile_default.sh + profile_collect.py -- attached only when
+    they were measured on THIS build of the library (the files carry the sources' hash); a kernel that
+    keeps its name across a tuning change must not be described by the old build's counters."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except (OSError, ValueError):
         return {}
+    from vaq_amd import build
+    if d.get("lib_source_hash") != build.source_hash():
+        return {}
+    return d
 
 
 def c5_leg(args, dev, device_index, k):
@@ -327,7 +337,7 @@ def c5_leg(args, dev, device_index, k):
                              "merge": round(tm["merge_ms"], 4)},
         "index_build_s": round(build_s, 1),
     }
-    tr = load_profile_json("r02_traffic.json").get("c5_stream")
+    tr = load_profile_json(PROFILE_ROUND + "_traffic.json").get("c5_stream")
     if tr and tr.get("rows") == N and tr.get("kernel") == kname:
         roof["traffic"] = tr["hbm_bytes_per_launch"]
         roof["traffic_source"] = tr["source"]
@@ -601,14 +611,14 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "workload": name + " (this run)",
                     "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4), "launches_timed": tm["n_searches"],
                     "algorithmic_bytes_per_launch": algo}
-        tr = load_profile_json("r02_traffic.json").get("c5_stream")
+        tr = load_profile_json(PROFILE_ROUND + "_traffic.json").get("c5_stream")
         if tr and tr.get("rows") == n_local and tr.get("kernel") == kname:
             roofline["traffic"] = tr["hbm_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
     else:
         # counter-based description of a cache-resident, pruned scan (separate rocprofv3 --pmc passes
         # of this same command: tools/profile_gpu.sh; the summary is committed under profiles/)
-        pm = load_profile_json("r02_bound.json").get(wl)
+        pm = load_profile_json(PROFILE_ROUND + "_bound.json").get(wl)
         if pm and world == 1 and not args.rows and not args.nq and not args.ti and pm.get("kernel") == kname:
             headline_kernel["bound"] = pm
 

@@ -8,7 +8,8 @@ set -o pipefail
 tag=$1; rows=$2; shift; shift
 pmc=0; [ "$1" = "pmc" ] && { pmc=1; shift; }
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export VAQHIP_LIB=$GRAFT_REPO_ROOT/vaq_amd/lib/libvaqhip.so
+python3 -m vaq_amd.build > /dev/null || exit 1
+export VAQ_NO_BUILD=1
 out=gpurun_out/prof_$tag
 mkdir -p $out
 ARGS="--rows $rows --skip-base --steps 3 $*"

@@ -8,6 +8,10 @@
 set -o pipefail
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# build BEFORE the profiler is in the process tree (hipcc / make children would be the exec-after-GPU-init
+# hop this pool forbids); the profiled commands then only check that the libraries exist
+python3 -m vaq_amd.build > /dev/null && make -s -C oracle all || exit 1
+export VAQ_NO_BUILD=1
 out=gpurun_out/prof_$tag
 mkdir -p $out
 BARGS="--steps 20 --warmup 5 ${BENCH_ARGS:-}"

@@ -73,6 +73,12 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     ones) and link them into libvaqhip.so."""
     if os.environ.get("VAQHIP_LIB") and not _VARIANT:
         return os.environ["VAQHIP_LIB"]  # a prebuilt experiment library was named: leave it alone
+    if os.environ.get("VAQ_NO_BUILD"):
+        # under rocprofv3 a child process (hipcc -> clang) is the exec-after-GPU-init hop the pool
+        # forbids: the library must have been built beforehand (tools/profile_*.sh do that)
+        if not os.path.exists(LIB):
+            raise FileNotFoundError(LIB + " is missing and VAQ_NO_BUILD is set: run `python -m vaq_amd.build` first")
+        return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -100,6 +106,19 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
     return LIB
+
+
+def source_hash() -> str:
+    """Identity of the library's sources (csrc + include): profile files under profiles/ carry it, and
+    bench.py only attaches their counter figures to a run of the SAME build."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
+    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_demo(force: bool = False) -> str:

@@ -1220,10 +1220,12 @@ static int set_codes_common(vaqhip_index *ix, const uint16_t *codes, bool on_dev
     }
     d_u16 = staged.as<uint16_t>();
   }
+  // (a search enqueued on another stream may still be scanning the rows this call rewrites)
+  if (int rc = ws_acquire(ix, st)) return rc;
   int rc = build_rows(ix, d_u16, N, st);  // synchronises: `staged` is freed on return
   if (rc) return rc;
   ix->id_base = id_base;
-  return VAQHIP_OK;
+  return ws_release(ix, st);
 }
 
 // append to a bucketed (non-TI) index: sort and pack the NEW rows only, then merge them into the
@@ -1630,6 +1632,8 @@ int vaqhip_index_set_ti_clusters(vaqhip_index *ix, const float *clusters, int T,
   if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
   if (T == 0 && ix->ti_T == 0) return VAQHIP_OK;
   hipStream_t st = ix->stream;
+  // (a search enqueued on another stream may still be scanning the rows this call regroups)
+  if (int rc = ws_acquire(ix, st)) return rc;
   // rows already handed over: recover them in original order, then regroup
   DevBuf rows;
   if (ix->N > 0) {
