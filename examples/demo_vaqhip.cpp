@@ -11,7 +11,7 @@
 //               [--groundtruth gt.ivecs] [--result out.csv] [--bits 8,8,...]
 //               [--visit-cluster 0.25]     (demo_vaq.cpp:43,57; with a ...,EA_TI<T>m<seg> method)
 //               [--ti-clusters c.f32]      (raw T x seg*L float32; default: random decoded rows)
-//               [--refine 100,200 --dataset-refine base.fvecs [--dataset-size N]]
+//               [--refine 100,200 --dataset base.fvecs [--dataset-size N]]   (or --dataset-refine)
 //                                          (demo_vaq.cpp:40, :312-345 and scripts/run_demos.sh:9,22: per value R,
 //                                           search R >= k candidates, then VAQ::refine re-ranks them against the
 //                                           raw vectors; results go to <result>_R<R> when several R are given)
@@ -90,9 +90,10 @@ int main(int argc, char **argv) {
     bool any_refine = false;
     for (const int r : refines) any_refine = any_refine || r >= k;
     if (any_refine) {
-      if (!a.count("dataset-refine")) throw Error(VAQHIP_EINVAL, "--refine needs --dataset-refine <raw vectors .fvecs>");
-      datasetrefine = readFVecs(a["dataset-refine"], N, a.count("dataset-size") ? std::atoi(a["dataset-size"].c_str()) : -1,
-                                0);
+      // the reference re-reads --dataset for this (demo_vaq.cpp:320-333); --dataset-refine names another file
+      const std::string raw = a.count("dataset-refine") ? a["dataset-refine"] : (a.count("dataset") ? a["dataset"] : "");
+      if (raw.empty()) throw Error(VAQHIP_EINVAL, "--refine needs the raw vectors: --dataset <.fvecs> (or --dataset-refine)");
+      datasetrefine = readFVecs(raw, N, a.count("dataset-size") ? std::atoi(a["dataset-size"].c_str()) : -1, 0);
     }
     RowMatrix<int> gt;
     if (a.count("groundtruth")) gt = readIVecs(a["groundtruth"], k);

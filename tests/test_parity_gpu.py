@@ -299,6 +299,72 @@ def test_cpp_demo_driver_refine_and_devices(vaqlib, oracle, tmp_path):
         assert np.allclose(d_got, o_dis, rtol=1e-6), R
 
 
+def test_run_demos_siftsmall_replay(vaqlib, oracle, tmp_path):
+    """BASELINE configs[0] / scripts/run_demos.sh:5-22 replayed through demo_vaqhip with the script's own
+    arguments: siftsmall shape (10 000 x 128 base, 100 queries), method VAQ256m32min7max8var1,HEAP,
+    --k 100 --refine 100,200.  The base is synthetic (siftsmall_base.fvecs is not in the checkout) and
+    the index comes from files, as training is out of scope: PCA + 32 codebooks of 256 from the harness,
+    rows encoded by the product's encoder, saved in the reference's --save / --save-enc formats.
+    Checked against oracle.search + oracle.refine for both refine values."""
+    import subprocess
+    import torch
+    import vaq_amd
+    from vaq_amd import build, harness, io
+    exe = build.build_demo()
+    N, nq, D, k = 10_000, 100, 128, 100
+    bits = [8] * 32  # a 256-bit budget over 32 subspaces of 7..8 bits: every subspace gets 8
+    base = harness.sift_like(N, D, stream=0, device="cuda")
+    queries = harness.sift_like(nq, D, stream=1, device="cuda")
+    E = harness.pca_eigenvectors(base)
+    cents = harness.train_codebooks(base @ E.to("cuda"), bits, iters=10)
+    v = vaq_amd.VaqHip()
+    v.parseMethodString("VAQ256m32min7max8var1,HEAP")
+    assert (v.mBitBudget, v.mSubspaceNum, v.mMinBitsPerSubs, v.mMaxBitsPerSubs) == (256, 32, 7, 8)
+    v.mBitsAlloc = bits
+    v.mCentroidsPerSubs = cents
+    v.mEigenVectors = E.numpy()
+    codes = v.encode_device(base, projected=False).cpu().numpy().view(np.uint16)
+    v.close()
+    base_h, q_h = base.cpu().numpy(), queries.cpu().numpy()
+    del base, queries
+    torch.cuda.empty_cache()
+    io.save_centroids(cents, str(tmp_path / "c.bin"))
+    io.save_codebook(codes, str(tmp_path / "cb.bin"))
+    E.numpy().astype(np.float32).tofile(str(tmp_path / "e.f32"))
+    io.write_vecs(str(tmp_path / "siftsmall_base.fvecs"), base_h)
+    io.write_vecs(str(tmp_path / "siftsmall_query.fvecs"), q_h)
+    gt = np.argsort(((q_h[:, None, :] - base_h[None, :, :]) ** 2).sum(-1), axis=1, kind="stable")[:, :k].astype(np.int32)
+    io.write_vecs(str(tmp_path / "siftsmall_groundtruth.ivecs"), gt)
+    method, refine = "VAQ256m32min7max8var1,HEAP", "100,200"
+    result = str(tmp_path / f"answer_vaq_{method}_refine{refine}_sift_10K.csv")
+    r = subprocess.run([exe, "--centroids", str(tmp_path / "c.bin"), "--codebook", str(tmp_path / "cb.bin"),
+                        "--eigen", str(tmp_path / "e.f32"),
+                        # scripts/run_demos.sh:11-22, argument for argument
+                        "--dataset", str(tmp_path / "siftsmall_base.fvecs"),
+                        "--queries", str(tmp_path / "siftsmall_query.fvecs"),
+                        "--file-format-ori", "fvecs", "--timeseries-size", "128", "--dataset-size", "10000",
+                        "--queries-size", "100", "--result", result,
+                        "--groundtruth", str(tmp_path / "siftsmall_groundtruth.ivecs"), "--groundtruth-format", "ivecs",
+                        "--method", method, "--k", "100", "--refine", refine],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "10000 rows x 32 subspaces" in r.stdout and "Refining the answer with Refine = 200" in r.stdout
+    for R in (100, 200):
+        got = np.loadtxt(result + f"_R{R}", delimiter=",", dtype=np.int64)
+        assert got.shape == (nq, k)
+        cand, _ = oracle.search(q_h, cents, codes, R, eig=E.numpy())
+        o_lab, o_dis = oracle.refine(q_h, base_h, cand, k)
+        d_got = ((q_h[:, None, :] - base_h[got]) ** 2).sum(-1).astype(np.float32)
+        assert np.allclose(d_got, o_dis, rtol=1e-6), R
+        # (integer-valued vectors: exact re-ranked distances tie; the candidate SETS must agree wherever
+        #  the oracle's distances are distinct at the boundary)
+        for qi in range(nq):
+            inner = o_dis[qi] < o_dis[qi, -1]
+            assert set(o_lab[qi][inner].tolist()) <= set(got[qi].tolist()), (R, qi)
+    rec = [float(x.split(":")[1]) for x in r.stdout.splitlines() if "precision(avg_recall)" in x]
+    assert len(rec) == 2 and rec[1] >= rec[0] > 0.5, rec  # refine 200 re-ranks a superset of refine 100's candidates
+
+
 @pytest.mark.parametrize("cfg", [CONFIGS[0], CONFIGS[1], CONFIGS[4], CONFIGS[5], CONFIGS[6], CONFIGS[10]],
                          ids=lambda c: str(c[0]))
 @pytest.mark.parametrize("bucket_bits", [1, 9, 10, 12])
