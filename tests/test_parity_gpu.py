@@ -133,6 +133,28 @@ def test_projection_tolerance(vaqlib, oracle):
     assert np.array_equal(Xp.view(np.uint32), oracle.project(c["X"], c["eig"]).view(np.uint32))
 
 
+@pytest.mark.parametrize("D,bits", [(128, [8] * 16), (64, [8] * 8), (256, [8] * 32), (96, [8] * 8)], ids=["d128", "d64", "d256", "d96"])
+def test_projection_many_rows_is_the_same_chain(vaqlib, oracle, D, bits):
+    """From 65 536 rows on the projection runs tiled (a workgroup takes 16-64 rows, project_tile_kernel);
+    every output is still one fmaf chain over the inner index ascending, so it equals the oracle's
+    fixed-order product bit for bit -- ragged last tile, a NaN row, and D = 96 (no tiled kernel: the
+    one-row-per-workgroup form)."""
+    rng = np.random.default_rng(5)
+    n = 65536 + 37
+    c = make_case(209, D, bits, 10, 4)
+    X = (rng.normal(size=(n, D)) * 30).astype(np.float32)
+    X[7, 3] = np.nan
+    v = make_index(c)
+    got = v.project(X)
+    want = oracle.project(X, c["eig"])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # and the encoder on top of it: code for code
+    X[7, 3] = 0.0
+    v.encode(X, projected=False)
+    want_codes = oracle.encode(oracle.project(X, c["eig"]), c["cents"], nthreads=8)
+    assert np.array_equal(np.asarray(v.mCodebook), want_codes)
+
+
 def test_edge_cases(vaqlib, oracle):
     import vaq_amd
     c = make_case(301, 32, [8] * 8, 50, 4)

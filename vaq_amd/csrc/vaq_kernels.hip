@@ -55,9 +55,66 @@ __global__ void project_kernel(const float *__restrict__ X, int D,
   }
 }
 
+// Many rows (the encoder's input: VAQ::encode projects the whole dataset, VAQ.cpp:294): a workgroup
+// takes RPT * (256 / D) rows, thread (h, c) keeps RPT outputs of column c in registers, the rows sit in
+// LDS and are read four inner indices at a time (one ds_read_b128, the same address for the whole
+// wave: a broadcast).  Every output is still ONE fmaf chain over the inner index ascending from 0,
+// so the result is bit for bit the one-row-per-workgroup kernel's; per four inner steps a thread
+// issues 4 loads of E, RPT LDS reads and 4 RPT FMAs.
+template <int D_, int RPT>
+__global__ __launch_bounds__(256) void project_tile_kernel(const float *__restrict__ X, int64_t n,
+                                                           const float *__restrict__ E, float *__restrict__ out,
+                                                           int checked) {
+  constexpr int G = 256 / D_, R = G * RPT;
+  __shared__ __attribute__((aligned(16))) float xs[R * D_];
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  for (int i = tid; i < R * D_ / 4; i += 256) {
+    const int64_t row = row0 + (i * 4) / D_;
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (row < n) v = reinterpret_cast<const float4 *>(X + row0 * D_)[i];
+    reinterpret_cast<float4 *>(xs)[i] = v;
+  }
+  __syncthreads();
+  const int c = tid % D_, h = tid / D_;
+  float acc[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; r++) acc[r] = 0.0f;
+  for (int j = 0; j < D_; j += 4) {
+    const float e0 = E[(size_t)(j + 0) * D_ + c], e1 = E[(size_t)(j + 1) * D_ + c];
+    const float e2 = E[(size_t)(j + 2) * D_ + c], e3 = E[(size_t)(j + 3) * D_ + c];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+      const float4 xv = *reinterpret_cast<const float4 *>(&xs[(h * RPT + r) * D_ + j]);
+      acc[r] = __builtin_fmaf(xv.x, e0, acc[r]);
+      acc[r] = __builtin_fmaf(xv.y, e1, acc[r]);
+      acc[r] = __builtin_fmaf(xv.z, e2, acc[r]);
+      acc[r] = __builtin_fmaf(xv.w, e3, acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; r++) {
+    const int64_t row = row0 + h * RPT + r;
+    float a = acc[r];
+    if (checked && !(fabsf(a) <= FLT_MAX)) a = 0.0f;
+    if (row < n) out[row * D_ + c] = a;
+  }
+}
+
+constexpr int64_t PROJECT_TILE_MIN_ROWS = 65536;
+
 hipError_t launch_project(const float *X, int64_t n, int D, const float *E, float *out,
                           hipStream_t st, int checked) {
   if (n == 0) return hipSuccess;
+  if (E && n >= PROJECT_TILE_MIN_ROWS && (D == 64 || D == 128 || D == 256)) {
+    constexpr int RPT = 16;
+    const int R = (256 / D) * RPT;
+    const dim3 grid((unsigned)((n + R - 1) / R));
+    if (D == 64) hipLaunchKernelGGL((project_tile_kernel<64, RPT>), grid, dim3(256), 0, st, X, n, E, out, checked);
+    else if (D == 128) hipLaunchKernelGGL((project_tile_kernel<128, RPT>), grid, dim3(256), 0, st, X, n, E, out, checked);
+    else hipLaunchKernelGGL((project_tile_kernel<256, RPT>), grid, dim3(256), 0, st, X, n, E, out, checked);
+    return hipGetLastError();
+  }
   // (one workgroup per row: batching 8 rows per workgroup, as the LUT build does with queries,
   //  was measured slower here -- 0.044 vs 0.030 ms for 10 k rows: too few workgroups to fill the chip)
   int threads = D < 256 ? ((D + 63) / 64) * 64 : 256;

@@ -27,6 +27,25 @@ def _rotation(d: int, seed: int, device) -> torch.Tensor:
     return q.to(torch.float32).to(device)
 
 
+_SIFT_CONSTANTS = {}
+
+
+def _sift_like_constants(d: int, seed: int, device: str, clusters: int):
+    """(lam, R, C) of sift_like: the same for every chunk of a base, so they are made once -- the QR
+    of the rotation and the centres are drawn on the CPU, and a 1B-row base is generated in a thousand
+    chunks."""
+    key = (d, seed, device, clusters)
+    if key not in _SIFT_CONSTANTS:
+        dev = torch.device(device)
+        lam = torch.arange(1, d + 1, dtype=torch.float64) ** -1.2
+        lam = (lam * d / lam.sum()).to(torch.float32).to(dev)
+        R = _rotation(d, seed, dev)
+        gc = torch.Generator(device="cpu").manual_seed(seed * 7 + 1)
+        C = (torch.randn(clusters, d, generator=gc, dtype=torch.float32)).to(dev) * lam.sqrt()
+        _SIFT_CONSTANTS[key] = (lam, R, C)
+    return _SIFT_CONSTANTS[key]
+
+
 def sift_like(n: int, d: int = 128, seed: int = SEED, stream: int = 0,
               device="cpu", chunk: int = 1 << 20, clusters: int = 1024,
               noise: float = 0.5) -> torch.Tensor:
@@ -39,11 +58,7 @@ def sift_like(n: int, d: int = 128, seed: int = SEED, stream: int = 0,
     recall@100 of about 0.3 on 1M rows, like SIFT1M), which a single Gaussian
     does not."""
     device = torch.device(device)
-    lam = torch.arange(1, d + 1, dtype=torch.float64) ** -1.2
-    lam = (lam * d / lam.sum()).to(torch.float32).to(device)
-    R = _rotation(d, seed, device)
-    gc = torch.Generator(device="cpu").manual_seed(seed * 7 + 1)
-    C = (torch.randn(clusters, d, generator=gc, dtype=torch.float32)).to(device) * lam.sqrt()
+    lam, R, C = _sift_like_constants(d, seed, str(device), clusters)
     out = torch.empty((n, d), dtype=torch.float32, device=device)
     g = torch.Generator(device=device).manual_seed(seed * 1000003 + stream)
     for s in range(0, n, chunk):
