@@ -247,7 +247,10 @@ struct BmParams {
   int *cnt;                  // [n_buckets] queries per bucket
   int *qoff;                 // [n_buckets + 1]
   int *fill;                 // [n_buckets]
-  int *qlist;                // [nq * n_buckets] (worst case) queries of bucket b at qoff[b]
+  int *qlist;                // [nq * n_buckets] (worst case) queries of bucket b at qoff[b], similar ones next to each other
+  unsigned short *qkey;      // [nq][1 << bucket_t] per query and group of second codes: its nearest and second nearest
+                             //      second code inside the group -- the bucket's list is ordered by it, so that the
+                             //      queries of a group of QB want the same runs of the bucket
   int *border;               // [n_buckets] buckets by descending work
   int *ioff;                 // [BM_XCDS][n_buckets / BM_XCDS + 2] prefix of the work items of each XCD's buckets
   unsigned *tickets;         // [BM_XCDS]

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
   __shared__ unsigned smask[BF_MAX_BUCKETS / 32];
   __shared__ unsigned shist[BM_HIST_BINS];
   __shared__ unsigned s_cnt[2];
+  __shared__ unsigned long long s_near[2 << GMIN_MAX_BITS];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int K0 = p.n_buckets, bt = p.bucket_t;
   const int nwords = K0 / 32;
@@ -96,6 +97,24 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
       }
     }
     __syncthreads();
+    {
+      // per group of second codes: the query's nearest and second nearest code of the group.  Queries
+      // that agree on them lie close together in the second subspace and reach the same runs of a
+      // bucket; the bucket lists are ordered by this key (bm_sort_kernel).
+      const int w = 8 - bt, ng = 1 << bt;
+      if (tid < 2 * ng) s_near[tid] = ~0ull;
+      __syncthreads();
+      const unsigned long long mine = ((unsigned long long)float_to_bits(l[256 + tid]) << 32) | (unsigned)tid;  // (256 threads: one second code each)
+      atomicMin(&s_near[tid >> w], mine);
+      __syncthreads();
+      if (mine != s_near[tid >> w]) atomicMin(&s_near[ng + (tid >> w)], mine);
+      __syncthreads();
+      if (tid < ng) {
+        const unsigned a = (unsigned)(s_near[tid] & 0xffu) & ((1u << w) - 1u);
+        const unsigned b2 = (unsigned)(s_near[ng + tid] & 0xffu) & ((1u << w) - 1u);
+        p.qkey[(size_t)q * ng + tid] = (unsigned short)((a << 8) | b2);
+      }
+    }
     const unsigned idx_mask = (unsigned)K0 - 1u;  // (K0 is a power of two >= 32)
     const unsigned empty_key = ~idx_mask;
     // the thread's buckets: their keys when still in reach, else 0xffffffff
@@ -364,8 +383,35 @@ __global__ __launch_bounds__(64) void bm_fill_kernel(BmParams p) {
     const int b = lane * 32 + __builtin_ctz(bits);
     bits &= bits - 1u;
     const int pos = atomicAdd(&p.fill[b], 1);
-    p.qlist[p.qoff[b] + pos] = q;
+    // (key << 14 | query: bm_sort_kernel orders the bucket's list by it and leaves the query alone)
+    p.qlist[p.qoff[b] + pos] = (int)(((unsigned)p.qkey[(size_t)q * (1 << p.bucket_t) + (b & ((1 << p.bucket_t) - 1))] << 14) | (unsigned)q);
   }
+}
+
+// One workgroup per bucket: its list ordered by (key, query) -- similar queries next to each other --
+// and stripped of the key.  Bitonic sort in LDS (a list holds at most one entry per query).
+constexpr int BM_SORT_THREADS = 256;
+__global__ __launch_bounds__(BM_SORT_THREADS) void bm_sort_kernel(BmParams p) {
+  extern __shared__ unsigned bs_keys[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = p.cnt[b];
+  if (n <= 0) return;
+  int *list = p.qlist + p.qoff[b];
+  int P = 2;
+  while (P < n) P <<= 1;
+  for (int i = tid; i < P; i += BM_SORT_THREADS) bs_keys[i] = i < n ? (unsigned)list[i] : 0xffffffffu;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (P >> 1); t += BM_SORT_THREADS) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const unsigned a = bs_keys[i], c = bs_keys[j];
+        if ((a > c) == ((i & size) == 0)) { bs_keys[i] = c; bs_keys[j] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += BM_SORT_THREADS) list[i] = (int)(bs_keys[i] & 0x3fffu);
 }
 
 // ---------------------------------------------------------------------------
@@ -894,6 +940,14 @@ hipError_t launch_bm_plan(const BmParams &p, hipStream_t st) {
   hipLaunchKernelGGL(bm_order_kernel, dim3(1), dim3(BM_MAX_THREADS), 0, st, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   hipLaunchKernelGGL(bm_fill_kernel, dim3(p.nq), dim3(64), 0, st, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  int P = 2;
+  while (P < p.nq) P <<= 1;
+  const size_t lds = (size_t)P * sizeof(unsigned);
+  if (p.nq > (1 << 14)) return hipErrorInvalidValue;  // (a list entry packs the query into 14 bits)
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(bm_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(bm_sort_kernel, dim3(p.n_buckets), dim3(BM_SORT_THREADS), lds, st, p);
   return hipGetLastError();
 }
 

@@ -519,8 +519,8 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
     HIP_TRY(ix->w_bm_qlist.ensure((size_t)chunk * K0 * sizeof(int)));
     HIP_TRY(ix->w_bm_cand_d.ensure((size_t)chunk * pl.bm_cap * sizeof(float)));
     HIP_TRY(ix->w_bm_cand_id.ensure((size_t)chunk * pl.bm_cap * sizeof(int)));
-    // per query: done_key, candidate count, scale, next done_key, fresh, histogram
-    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (5 + vaq::BM_HIST_BINS) * 4));
+    // per query: done_key, candidate count, scale, next done_key, fresh, histogram, list keys (16 x 2 bytes)
+    HIP_TRY(ix->w_bm_query.ensure((size_t)chunk * (5 + vaq::BM_HIST_BINS + 8) * 4));
     HIP_TRY(ix->w_bm_thr64.ensure((size_t)chunk * sizeof(unsigned long long)));
     // overflowed queries are finished by the best-first form's second launch
     HIP_TRY(ix->w_defer.ensure(16 + (size_t)chunk * sizeof(vaq::DeferRec)));
@@ -765,6 +765,7 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
       bp.done_next = qw + (size_t)3 * chunk;
       bp.fresh = qw + (size_t)4 * chunk;
       bp.hist = qw + (size_t)5 * chunk;
+      bp.qkey = reinterpret_cast<unsigned short *>(qw + (size_t)(5 + vaq::BM_HIST_BINS) * chunk);
       bp.limit = 0;
       bp.retry = 0;
       HIP_TRY(hipMemsetAsync(bp.fresh, 0, (size_t)n * 4, st));
