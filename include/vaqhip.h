@@ -351,7 +351,7 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       order (one workgroup per such query: cheap at 1M rows, about a second per
  *                       query at 1B).  HEAP / EA without TI, k < 1024; labels and distances are then
  *                       identical to VAQ::search's, slot for slot.
- *   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 128
+ *   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 8
  *                       queries in the call, the best-first pass is cut after each query's nearest
  *                       buckets and what is left in reach is scanned bucket by bucket: a bucket's
  *                       rows are streamed once for ALL the queries that still want it, four

@@ -140,7 +140,15 @@ def test_c4_100m_rows(vaqlib, oracle):
     base = search_np(v, Xd, k)
     t = v.last_timing()
     v.set_option("timing", 0)
-    assert t["slices"] > 1, t  # the auto plan cuts 100M rows into slices
+    assert t["bucket_major"] == 1, t  # 32 queries on 800 MB of codes: the bucket-major rounds
+    v.set_option("bucket_major", 0)
+    v.set_option("timing", 1)
+    old = search_np(v, Xd, k)
+    t = v.last_timing()
+    v.set_option("timing", 0)
+    assert t["bucket_major"] == 0 and t["slices"] > 1, t  # ... and without them the plan cuts 100M rows into slices
+    assert np.array_equal(old[0], base[0]) and np.array_equal(old[1].view(np.uint32), base[1].view(np.uint32))
+    v.set_option("bucket_major", 1)
     check_sorted_unique(base[0], base[1], N, k)
     host = c["codes"].cpu().numpy().view(np.uint16)
     check_oracle(oracle, c, host, base[0], base[1], 4, k, "c4 100M")
@@ -166,10 +174,15 @@ def test_c5_cut_64m_rows(vaqlib, oracle):
     v = index_of(c, c["codes"])
     Xd = torch.from_numpy(c["X"]).cuda()
     v.set_option("timing", 1)
+    auto = search_np(v, Xd, k)
+    assert v.last_timing()["bucket_major"] == 1  # (from 8 queries on: the bucket-major rounds)
+    v.set_option("bucket_major", 0)
     base = search_np(v, Xd, k)
     t32 = v.last_timing()
+    assert np.array_equal(auto[0], base[0]) and np.array_equal(auto[1].view(np.uint32), base[1].view(np.uint32))
     l2, d2 = search_np(v, Xd[:2].contiguous(), k)
     t2 = v.last_timing()
+    v.set_option("bucket_major", 1)
     v.set_option("timing", 0)
     assert t32["queries_per_pass"] == 4 and t32["seed_slices"] > 0 and t32["early_abandon"] == 1, t32
     assert t2["queries_per_pass"] == 2 and t2["early_abandon"] == 2 and t2["seed_slices"] > 0, t2

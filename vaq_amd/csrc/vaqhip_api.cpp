@@ -90,7 +90,8 @@ constexpr int INPLACE_MAX_BATCHES = 4;         // query batches per scan up to w
 // Bucket-major second pass (vaq_scan_bm.hip): a streamed database and so many queries that every
 // bucket is wanted by several of them.  Pass A (best-first, one workgroup per query) is cut after
 // about one average bucket's worth of work units; BM_CAND_CAP candidate slots per query.
-constexpr int BM_MIN_QUERIES = 128;
+constexpr int BM_MIN_QUERIES = 8;   // (125M x 16 B: 1 / 2 / 8 / 32 queries 0.45 / 0.58 / 1.15 / 2.44 ms with the shared-stream forms,
+                                    //  0.63 / 0.63 / 0.72 / 0.87 ms with the rounds -- a chain of ~20 launches is their floor)
 constexpr int BM_CAND_CAP = 4096;
 constexpr int BM_QB = 4, BM_NWAVES = 16;
 constexpr int BM_BOOT_MIN_UNITS = 24;
