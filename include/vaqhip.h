@@ -348,9 +348,10 @@ int vaqhip_index_info(const vaqhip_index *ix, vaqhip_info *out);
  *                       its heap (VAQ.cpp:1750-1757, utils/Heap.hpp:115-169, 322-349).  The scan runs
  *                       with k + 1; a query whose k + 1 smallest distances are distinct is unaffected,
  *                       every other query is replayed through that heap over ALL rows in original
- *                       order (one workgroup per such query: cheap at 1M rows, about a second per
- *                       query at 1B).  HEAP / EA without TI, k < 1024; labels and distances are then
- *                       identical to VAQ::search's, slot for slot.
+ *                       order (one workgroup per such query: 1M rows x 10 k queries, nine in ten of
+ *                       them with ties: 0.65 -> 43 ms; about a second per tied query at 1B rows).
+ *                       HEAP / EA without TI, k < 1024; labels and distances are then identical to
+ *                       VAQ::search's, slot for slot.
  *   "bucket_major"      1 (default): on a streamed database (> 128 MB of byte codes) with at least 8
  *                       queries in the call, the best-first pass is cut after each query's nearest
  *                       buckets and what is left in reach is scanned bucket by bucket: a bucket's

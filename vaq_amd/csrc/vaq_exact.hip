@@ -76,6 +76,8 @@ struct ExactParams {
   int layout, M, W;
   const SubDesc *sub;
   const uint32_t *inv;  // original row -> row of the bucketed order (nullptr = identity)
+  const unsigned short *row_bucket;  // original row -> its bucket (nullptr: no bucket pruning)
+  int n_buckets, bucket_shift, bucket_t;
   int64_t n_rows;
   const float *lut;     // [nq][lut_floats]
   int lut_floats;
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(EX_THREADS) void exact_replay_kernel(ExactParams p)
   float *hval = reinterpret_cast<float *>(ex_smem);
   int *hid = reinterpret_cast<int *>(hval + k);
   float *buf = reinterpret_cast<float *>(hid + k);  // [2][EX_CHUNK]
-  float *lds_lut = buf + 2 * EX_CHUNK;
+  float *lbound = buf + 2 * EX_CHUNK;              // [n_buckets] lower bound of the row sums of each bucket (row_bucket)
+  float *lds_lut = lbound + (p.row_bucket ? p.n_buckets : 0);
   const float *glut = p.lut + (size_t)q * p.lut_floats;
   const float *lut = glut;
   if (p.lut_in_lds) {
@@ -173,7 +176,37 @@ __global__ __launch_bounds__(EX_THREADS) void exact_replay_kernel(ExactParams p)
   // the heap top after the last COMPLETE pop + push, for the evaluating waves (the root itself passes
   // through values below the new top while a pop is under way)
   __shared__ float s_top;
+  __shared__ unsigned s_gmin[1 << GMIN_MAX_BITS];
   if (tid == 0) s_top = FLT_MAX;
+  if (p.row_bucket) {
+    // Per bucket the smallest sum its rows can have -- the first table term, plus the smallest second
+    // term of the bucket's group of second codes, or the minimum over a coarse bucket's first codes:
+    // the bound the scan kernels order the buckets by.  A row whose bucket's bound is not below the
+    // heap top cannot be admitted (every further term is >= 0 and fp32 addition is monotone), so its
+    // codes are not even read.
+    const int bt = p.bucket_t, bsh = p.bucket_shift;
+    if (tid < (1 << GMIN_MAX_BITS)) s_gmin[tid] = 0x7f800000u;
+    __syncthreads();
+    if (bt > 0) {
+      const int off1 = p.sub[1].lut_off, n1 = p.sub[1].ncent;
+      const int w = 31 - __builtin_clz((unsigned)n1) - bt;
+      for (int e = tid; e < n1; e += EX_THREADS) atomicMin(&s_gmin[e >> w], float_to_bits(glut[off1 + e]));
+      __syncthreads();
+    }
+    for (int b = tid; b < p.n_buckets; b += EX_THREADS) {
+      float m;
+      if (bt > 0) {
+        m = glut[b >> bt] + bits_to_float(s_gmin[b & ((1 << bt) - 1)]);
+      } else {
+        m = INFINITY;
+        for (int c = b << bsh; c < ((b + 1) << bsh); c++) {
+          const float x = glut[c];
+          m = x < m ? x : m;
+        }
+      }
+      lbound[b] = m == m ? m : -INFINITY;  // (a NaN table: never prune by it)
+    }
+  }
   __syncthreads();
   const int64_t N = p.n_rows;
   const int64_t nchunks = (N + EX_CHUNK - 1) / EX_CHUNK;
@@ -184,11 +217,27 @@ __global__ __launch_bounds__(EX_THREADS) void exact_replay_kernel(ExactParams p)
         //  top any row of the chunk will meet -- an admissible row is never abandoned)
         const float t = __hip_atomic_load(&s_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         float *out = buf + (c & 1) * EX_CHUNK;
-        for (int j = tid - 64; j < EX_CHUNK; j += EX_THREADS - 64) {
+        constexpr int RPT = (EX_CHUNK + EX_THREADS - 64 - 1) / (EX_THREADS - 64);
+        // first the cheap test for all of the thread's rows (one coalesced halfword + one LDS word each),
+        // then the gathers of the survivors, all issued before the first sum
+        bool live[RPT];
+        int64_t src[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+          const int j = tid - 64 + i * (EX_THREADS - 64);
           const int64_t row = c * EX_CHUNK + j;
-          float d = INFINITY;
-          if (row < N) d = ex_row_dist<BYTES>(p, lut, p.inv ? (int64_t)p.inv[row] : row, t);
-          out[j] = d;
+          live[i] = j < EX_CHUNK && row < N;
+          if (live[i] && p.row_bucket) live[i] = lbound[p.row_bucket[row]] < t;
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+          const int64_t row = c * EX_CHUNK + (tid - 64 + i * (EX_THREADS - 64));
+          src[i] = live[i] ? (p.inv ? (int64_t)p.inv[row] : row) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+          const int j = tid - 64 + i * (EX_THREADS - 64);
+          if (j < EX_CHUNK) out[j] = live[i] ? ex_row_dist<BYTES>(p, lut, src[i], t) : INFINITY;
         }
       }
     } else if (c > 0) {
@@ -243,19 +292,36 @@ __global__ __launch_bounds__(EX_THREADS) void exact_replay_kernel(ExactParams p)
   }
 }
 
-__global__ void inverse_perm_kernel(const uint32_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ inv) {
+// inv[original row] = row of the bucketed order; row_bucket[original row] = its bucket (optional)
+__global__ void inverse_perm_kernel(const uint32_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ inv,
+                                    const int *__restrict__ bucket_start, int n_buckets,
+                                    unsigned short *__restrict__ row_bucket) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n) inv[perm[r]] = (uint32_t)r;
+  if (r >= n) return;
+  const uint32_t lab = perm ? perm[r] : (uint32_t)r;
+  inv[lab] = (uint32_t)r;
+  if (row_bucket) {
+    int lo = 0, hi = n_buckets;  // largest b with bucket_start[b] <= r
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)bucket_start[mid] <= r) lo = mid;
+      else hi = mid;
+    }
+    row_bucket[lab] = (unsigned short)lo;
+  }
 }
 
-hipError_t launch_inverse_perm(const uint32_t *perm, int64_t n, uint32_t *inv, hipStream_t st) {
+hipError_t launch_inverse_perm(const uint32_t *perm, int64_t n, uint32_t *inv, const int *bucket_start, int n_buckets,
+                               unsigned short *row_bucket, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(inverse_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, n, inv);
+  hipLaunchKernelGGL(inverse_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, n, inv, bucket_start,
+                     n_buckets, row_bucket);
   return hipGetLastError();
 }
 
 // in_labels / in_dist: the scan's result for k + 1 per query; labels / dist: the caller's k per query
 hipError_t launch_exact_ties(const uint32_t *codes, int layout, int M, int W, const SubDesc *sub, const uint32_t *inv,
+                             const unsigned short *row_bucket, int n_buckets, int bucket_shift, int bucket_t,
                              int64_t n_rows, const float *lut, int lut_floats, int nq, int k, int64_t id_base,
                              const int32_t *in_labels, const float *in_dist, int32_t *labels, float *dist, int *list,
                              unsigned *count, hipStream_t st) {
@@ -267,6 +333,10 @@ hipError_t launch_exact_ties(const uint32_t *codes, int layout, int M, int W, co
   p.W = W;
   p.sub = sub;
   p.inv = inv;
+  p.row_bucket = row_bucket;
+  p.n_buckets = n_buckets;
+  p.bucket_shift = bucket_shift;
+  p.bucket_t = bucket_t;
   p.n_rows = n_rows;
   p.lut = lut;
   p.lut_floats = lut_floats;
@@ -284,7 +354,7 @@ hipError_t launch_exact_ties(const uint32_t *codes, int layout, int M, int W, co
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(exact_flag_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  size_t lds = (size_t)k * 8 + (size_t)2 * EX_CHUNK * 4;
+  size_t lds = (size_t)k * 8 + (size_t)2 * EX_CHUNK * 4 + (row_bucket ? (size_t)n_buckets * 4 : 0);
   p.lut_in_lds = (size_t)lut_floats * 4 + lds <= 96 * 1024 ? 1 : 0;
   if (p.lut_in_lds) lds += (size_t)lut_floats * 4;
   if (layout == LAYOUT_BYTES) {

@@ -284,12 +284,14 @@ hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st);
 hipError_t launch_bm_select(const BmParams &p, hipStream_t st);
 
 // ---- the reference's own choice among rows of equal distance (vaq_exact.hip, option "exact_ties") ----
-// inv[original row] = row of the bucketed order
-hipError_t launch_inverse_perm(const uint32_t *perm, int64_t n, uint32_t *inv, hipStream_t st);
+// inv[original row] = row of the bucketed order; row_bucket (optional): [original row] = its bucket
+hipError_t launch_inverse_perm(const uint32_t *perm, int64_t n, uint32_t *inv, const int *bucket_start, int n_buckets,
+                               unsigned short *row_bucket, hipStream_t st);
 // in_labels / in_dist: the scan's result for k + 1 per query (labels carry id_base); labels / dist: the
 // caller's k per query.  Queries whose k + 1 smallest distances are distinct are copied; the others
 // are replayed through the reference's heap in original row order.  list: [nq] ints, count: one word.
 hipError_t launch_exact_ties(const uint32_t *codes, int layout, int M, int W, const SubDesc *sub, const uint32_t *inv,
+                             const unsigned short *row_bucket, int n_buckets, int bucket_shift, int bucket_t,
                              int64_t n_rows, const float *lut, int lut_floats, int nq, int k, int64_t id_base,
                              const int32_t *in_labels, const float *in_dist, int32_t *labels, float *dist, int *list,
                              unsigned *count, hipStream_t st);

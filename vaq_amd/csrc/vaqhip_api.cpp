@@ -129,7 +129,7 @@ struct vaqhip_index {
   DevBuf w_bm_small, w_bm_mask, w_bm_qlist, w_bm_cand_d, w_bm_cand_id, w_bm_query, w_bm_thr64;
   // option "exact_ties": original row -> bucketed row (built at the first such search after the codes change),
   // the scan's k + 1 results, the replay list
-  DevBuf d_inv, w_ex_labels, w_ex_dist, w_ex_list;
+  DevBuf d_inv, d_rowbucket, w_ex_labels, w_ex_dist, w_ex_list;
   bool inv_valid = false;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
@@ -950,7 +950,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
   HIP_TRY(ix->w_ex_list.ensure((size_t)chunk * sizeof(int) + 16));
   if (ix->N > 0 && !ix->inv_valid) {
     HIP_TRY(ix->d_inv.ensure((size_t)ix->N * sizeof(uint32_t)));
-    HIP_TRY(vaq::launch_inverse_perm(ix->d_perm.as<uint32_t>(), ix->N, ix->d_inv.as<uint32_t>(), st));
+    HIP_TRY(ix->d_rowbucket.ensure((size_t)ix->N * sizeof(unsigned short)));
+    HIP_TRY(vaq::launch_inverse_perm(ix->d_perm.as<uint32_t>(), ix->N, ix->d_inv.as<uint32_t>(), ix->d_bstart.as<int>(),
+                                     ix->n_buckets, ix->d_rowbucket.as<unsigned short>(), st));
     ix->inv_valid = true;
   }
   for (int q0 = 0; q0 < nq; q0 += chunk) {
@@ -961,7 +963,9 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     rc = ws_acquire(ix, st);
     if (rc) return rc;
     HIP_TRY(vaq::launch_exact_ties(ix->d_codes.as<uint32_t>(), ix->layout, ix->M, ix->W, ix->d_sub.as<vaq::SubDesc>(),
-                                   ix->d_inv.as<uint32_t>(), ix->N, ix->w_lut.as<float>(), ix->lut_floats, n, k, ix->id_base,
+                                   ix->d_inv.as<uint32_t>(), ix->N > 0 ? ix->d_rowbucket.as<unsigned short>() : nullptr,
+                                   ix->n_buckets, ix->bucket_shift, ix->bucket_t, ix->N, ix->w_lut.as<float>(), ix->lut_floats, n,
+                                   k, ix->id_base,
                                    ix->w_ex_labels.as<int32_t>(), ix->w_ex_dist.as<float>(), d_labels + (size_t)q0 * k,
                                    d_dist + (size_t)q0 * k, reinterpret_cast<int *>(ix->w_ex_list.as<unsigned char>() + 16),
                                    ix->w_ex_list.as<unsigned>(), st));
