@@ -368,6 +368,9 @@ def c5_leg(args, dev, device_index, k):
         "pre_pass_ms": round(tm3["seed_ms"], 3), "merge_ms": round(tm3["merge_ms"], 3),
         "queries_per_pass": tm3["queries_per_pass"], "passes": tm3["passes"],
     }
+    pm = load_profile_json(PROFILE_ROUND + "_bound.json").get("c5_bm")
+    if pm and pm.get("rows") == N and pm.get("queries") == nq_full and tm3.get("bucket_major"):
+        scale_base["counters"] = pm
     scale_base["form"] = ("bucket-major rounds (vaq_scan_bm.hip): every bucket streamed once for all the queries that "
                           "reach it" if tm3.get("bucket_major") else "one best-first workgroup per (query, slice)")
     assert bool(torch.equal(outf[0][:2], stream_labels) and torch.equal(outf[1][:2], stream_dists)), \
@@ -764,6 +767,15 @@ def main():
     scale_base = None
     if world == 1 and args.workload == "auto" and not args.no_c5_leg and not args.ti:
         roofline, scale_base = c5_leg(args, dev, local_rank, k)
+    if roofline is None and tm.get("bucket_major"):
+        roofline = {"bound": "valu issue (bucket-major rounds: a bucket's rows cross HBM once and are served to the other "
+                             "query groups from the XCD's L2, so the HBM roofline does not bind; counters under profiles/)",
+                    "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": kname, "kernel_ms": round(tm["scan_ms"], 4)}
+        pm = load_profile_json(PROFILE_ROUND + "_bound.json").get("c5_bm")
+        if pm and pm.get("rows") == n_local and pm.get("queries") == nq_local:
+            roofline["counters"] = pm
+            roofline["traffic"] = pm.get("memory_side_bytes_per_step")
     if roofline is None:
         roofline = {"bound": "lds+issue (cache-resident, bucket-pruned scan: no HBM roofline applies)",
                     "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,

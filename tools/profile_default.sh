@@ -22,7 +22,8 @@ echo "kernel trace done"; head -4 $out/kernel_stats.csv | cut -c1-160
 [ "$1" = "pmc" ] || exit 0
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
-            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
+            "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
+            "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $pass --kernel-include-regex "scan_" --output-format csv -d $out/pmc_$name -- python3 bench.py $BARGS --no-cpu --no-recall > /dev/null 2> $out/pmc_$name.err || { echo "pmc pass failed: $pass"; tail -3 $out/pmc_$name.err; continue; }
   f=$(find $out/pmc_$name -name "*counter_collection.csv" | head -1)

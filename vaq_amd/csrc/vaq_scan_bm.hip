@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void bm_mark_kernel(BmParams p) {
 // there up to BM_BOOT_ROWS rows summed completely; their k-th smallest sum has k real rows at or below
 // it -- an upper bound of the final k-th distance (FLT_MAX when the sample has fewer than k rows).
 // The query's result list starts empty and none of its buckets is finished.
-constexpr int BM_BOOT_ROWS = 4096;
+#ifndef VAQ_BM_BOOT_ROWS
+#define VAQ_BM_BOOT_ROWS 4096
+#endif
+constexpr int BM_BOOT_ROWS = VAQ_BM_BOOT_ROWS;
 template <int M>
 __global__ __launch_bounds__(256) void bm_boot_kernel(BmParams p) {
   constexpr int WPR = M / 4;
