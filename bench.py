@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "queries"],
                     help="multi-GPU: shard code rows (all-gather + merge; default), or replicate codes and shard queries")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--exchange-thresholds", type=int, default=1,
+                    help="rows mode, N > 1: all-reduce(MIN) the per-query thresholds between the first rounds and the rest "
+                         "of the search (0: every shard on its own)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     return ap.parse_args()
@@ -516,8 +519,19 @@ def main():
     # device time of the exchange step, per step: events on the stream everything is enqueued on
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)] if collective else None
 
+    # rows mode: every shard finds ITS k best -- one all-reduce(MIN) of the nq thresholds between the
+    # first rounds and the rest lets each shard scan only what the GLOBAL k-th distance allows
+    # (vaq_amd/sharding.py "Threshold exchange"); all ranks must agree on taking that path
+    staged = bool(collective and mode == "rows" and args.exchange_thresholds and not args.ti and
+                  sharding.staged_agreed(v, nq_local, k))
+    thr_buf = torch.empty((nq_local,), dtype=torch.int32, device=dev) if staged else None
+
     def run_step(i=-1):
-        l, d = v.search_device(my_queries, k, out=out_local)
+        if staged:
+            sharding.search_staged(v, my_queries, k, out_local, thr_buf, host_bounce=args.backend != "nccl")
+            l, d = out_local
+        else:
+            l, d = v.search_device(my_queries, k, out=out_local)
         if collective:
             if i >= 0:
                 ev[i][0].record()
@@ -570,6 +584,8 @@ def main():
             "world": world, "collective": "all_gather_into_tensor of one packed [2][nq][k] int32 buffer per rank "
                                           "(%s)" % ("RCCL" if args.backend == "nccl" else args.backend),
             "bytes_per_rank": int(2 * n_pack * k * 4),
+            "threshold_exchange": ("all-reduce(MIN) of %d int32 thresholds between the first rounds and the rest of every "
+                                   "shard's search" % nq_local) if staged else "none",
             "collective_ms": round(float(allst[:, 1].max()), 4), "merge_ms": round(float(allst[:, 2].max()), 4),
             "scan_ms_per_rank": [round(float(x), 4) for x in allst[:, 3]],
             "rows_local": [int(x) for x in allst[:, 4]],

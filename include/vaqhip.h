@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define VAQHIP_VERSION 103
+#define VAQHIP_VERSION 104
 
 /* error codes */
 #define VAQHIP_OK            0
@@ -166,6 +166,26 @@ int vaqhip_search_projected(vaqhip_index *ix, const float *qproj_rowmajor, int n
 int vaqhip_search_device(vaqhip_index *ix, const float *d_queries, int nq, int k,
                          int projected, int32_t *d_labels, float *d_distances,
                          void *stream);
+
+/* Staged search for hosts that shard the rows over several GPUs, one process (or index) per GPU: every
+ * shard finds ITS k best, so on its own its admission thresholds are looser than the global k-th
+ * distance allows.  `begin` runs the first rounds of the search (each query's nearest buckets) and
+ * writes the thresholds they leave -- nq distance bit patterns, int32, ordered like the distances --
+ * to d_thresholds_out; the caller takes the element-wise MINIMUM over all shards (one all-reduce of
+ * 4 * nq bytes: a threshold is an upper bound of the query's final k-th distance, and any shard's
+ * bound holds everywhere, the k rows behind it exist) and hands it to `finish`, which scans what is
+ * still in reach under it.  A shard may then return fewer than k rows for a query (slots -1 / FLT_MAX):
+ * the merge of the shards' lists (vaqhip_merge_topk_*) is the global result, bit for bit what one
+ * index over all rows returns.  d_labels / d_distances of `begin` hold intermediate lists until `finish`
+ * returns; no other call on the index in between (VAQHIP_ESTATE).  VAQHIP_EUNSUPPORTED when the search
+ * would not run the bucket-major rounds (few queries, cache-resident or bit-packed rows, TI): use
+ * vaqhip_search_device then -- vaqhip_search_staged_supported tells beforehand, so that all shards can
+ * agree.  d_thresholds_in may be NULL (no exchange).  Replaces nothing in the reference (its search is
+ * one process on one host, VAQ.cpp:776); it is the exchange step SURVEY 8(e) allows for. */
+int vaqhip_search_staged_supported(vaqhip_index *ix, int nq, int k);
+int vaqhip_search_begin_device(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                               int32_t *d_labels, float *d_distances, int32_t *d_thresholds_out, void *stream);
+int vaqhip_search_finish_device(vaqhip_index *ix, const int32_t *d_thresholds_in, void *stream);
 
 /* Test hook for VAQ::CreateLUT<maxbit> (VAQ.hpp:128-167): writes, per query,
  * the reference LUTType (column-major ksub x M, ksub = 1 << max(bits), rows

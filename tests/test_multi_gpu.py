@@ -137,3 +137,61 @@ def test_multi_search_device_entry(vaqlib):
         r = ref.search(c["X"][:n], k)
         assert np.array_equal(l.cpu().numpy().ravel(), r.labels) and np.array_equal(d.cpu().numpy().ravel().view(np.uint32), r.distances.view(np.uint32))
     m.close()
+
+
+@pytest.mark.parametrize("bits,N,nq", [([8] * 16, 1_200_000, 64), ([8] * 8, 900_000, 40)], ids=["m16", "m8"])
+def test_staged_search_with_threshold_exchange(vaqlib, oracle, bits, N, nq):
+    """vaqhip_search_begin_device / _finish_device on three row shards (three indexes on the one GPU):
+    the thresholds each shard's first rounds leave are MIN-reduced (here with torch), every shard
+    finishes under the global bound (less of it is in reach then; its list keeps what the first
+    rounds found), and the merge of the three lists equals the single index bit for bit.  Also: no
+    exchange (NULL), a second staged search on the same index, and the state errors."""
+    import torch
+    import vaq_amd
+    from vaq_amd import _lib
+    from vaq_amd.index import merge_topk_packed_device
+    from vaq_amd.sharding import shard_bounds
+    k, G = 50, 3
+    c = make_case(4500 + len(bits), 8 * len(bits), bits, N, nq, dup_frac=0.02)
+    ref = single(c)
+    ref.set_option("bucket_major", 2)
+    r = ref.search(c["X"], k)
+    shards = []
+    for g in range(G):
+        lo, hi = shard_bounds(N, G, g)
+        v = vaq_amd.VaqHip()
+        v.mBitsAlloc = list(bits)
+        v.mCentroidsPerSubs = c["cents"]
+        v.mEigenVectors = c["eig"]
+        v.mCodebook = c["codes"][lo:hi]
+        v.id_base = lo
+        v.set_option("bucket_major", 2)
+        assert v.staged_supported(nq, k)
+        shards.append(v)
+    Xd = torch.from_numpy(c["X"]).cuda()
+    for exchange in (True, False, True):
+        packed = torch.empty((G, 2, nq, k), dtype=torch.int32, device="cuda")
+        thr = torch.empty((G, nq), dtype=torch.int32, device="cuda")
+        for g, v in enumerate(shards):
+            v.search_begin_device(Xd, k, (packed[g, 0], packed[g, 1].view(torch.float32)), thr[g])
+        # a second search while one is open is refused, and leaves the open one intact
+        with pytest.raises(_lib.VaqHipError) as e:
+            shards[0].search(c["X"], k)
+        assert e.value.code == -7
+        tmin = thr.min(dim=0).values.contiguous()
+        assert (tmin >= 0).all()
+        for g, v in enumerate(shards):
+            v.search_finish_device(tmin if exchange else None)
+        torch.cuda.synchronize()
+        ml, md = merge_topk_packed_device(packed, G, nq, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(ml.cpu().numpy().ravel(), r.labels)
+        assert np.array_equal(md.cpu().numpy().ravel().view(np.uint32), r.distances.view(np.uint32))
+    with pytest.raises(_lib.VaqHipError) as e:
+        shards[0].search_finish_device(None)  # nothing open
+    assert e.value.code == -7
+    # a plan without the rounds cannot be staged
+    small = single(dict(c, codes=c["codes"][:5000]))
+    assert not small.staged_supported(nq, k)
+    for v in shards:
+        v.close()

@@ -17,7 +17,8 @@ SYMBOLS = [
     "vaqhip_index_set_codes_u16_device", "vaqhip_index_add_codes_u16", "vaqhip_index_add_codes_u16_device",
     "vaqhip_index_set_ti_clusters", "vaqhip_index_set_method",
     "vaqhip_search", "vaqhip_search_projected",
-    "vaqhip_search_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
+    "vaqhip_search_device", "vaqhip_search_staged_supported", "vaqhip_search_begin_device",
+    "vaqhip_search_finish_device", "vaqhip_build_lut", "vaqhip_project", "vaqhip_merge_topk_device",
     "vaqhip_merge_topk_strided_device",
     "vaqhip_encode", "vaqhip_encode_device", "vaqhip_refine", "vaqhip_refine_device",
     "vaqhip_index_info", "vaqhip_set_option", "vaqhip_last_timing", "vaqhip_last_error",
@@ -107,6 +108,9 @@ def load():
     L.vaqhip_search.argtypes = [vp, vp, i32, i32, vp, vp]
     L.vaqhip_search_projected.argtypes = [vp, vp, i32, i32, vp, vp]
     L.vaqhip_search_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.vaqhip_search_staged_supported.argtypes = [vp, i32, i32]
+    L.vaqhip_search_begin_device.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.vaqhip_search_finish_device.argtypes = [vp, vp, vp]
     L.vaqhip_build_lut.argtypes = [vp, vp, i32, i32, vp]
     L.vaqhip_project.argtypes = [vp, vp, i64, vp]
     L.vaqhip_merge_topk_device.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]

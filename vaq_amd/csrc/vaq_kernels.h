@@ -280,6 +280,9 @@ hipError_t launch_bm_plan(const BmParams &p, hipStream_t st);
 // smallest complete sum of up to 4096 rows starting at the nearest run of the nearest bucket), an empty
 // result list, nothing finished (the first round is then planned with BmParams::first = 1)
 hipError_t launch_bm_boot(const BmParams &p, int64_t n_rows, hipStream_t st);
+// staged search: thr64 = min(thr64, thr_in << 32 | 0x7fffffff) (thr_in optional); thr_out (optional) = distance bits
+// of thr64; init: thr64 is first made from g_thr
+hipError_t launch_bm_thresholds(const BmParams &p, const int32_t *thr_in, int32_t *thr_out, int init, hipStream_t st);
 hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st);
 hipError_t launch_bm_select(const BmParams &p, hipStream_t st);
 

@@ -918,6 +918,28 @@ size_t bm_plan_small_words(int n_buckets) {
   return (size_t)n_buckets * 4 + 1 + (size_t)BM_XCDS * bm_ioff_stride(n_buckets) + BM_XCDS;
 }
 
+// Staged search: the thresholds (distance bits; >= 0, so ordered like the values) leave the index for the
+// exchange between shards and come back as the minimum over all of them.  A threshold is an upper bound
+// of the query's final k-th distance, and any shard's bound holds for every shard: the k rows behind it
+// exist, wherever they are.  Label bounds are shard-local and are not exchanged (rows AT the exchanged
+// distance stay admissible).
+__global__ void bm_thresholds_kernel(BmParams p, const int32_t *__restrict__ thr_in, int32_t *__restrict__ thr_out, int init) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.nq) return;
+  if (init) p.thr64[q] = ((unsigned long long)p.g_thr[q] << 32) | 0x7fffffffull;
+  if (thr_in) {
+    atomicMin(&p.thr64[q], ((unsigned long long)(unsigned)thr_in[q] << 32) | 0x7fffffffull);
+    atomicMin(&p.g_thr[q], (unsigned)thr_in[q]);  // (what a first round still to come, and the best-first fallback, start from)
+  }
+  if (thr_out) thr_out[q] = (int32_t)(p.thr64[q] >> 32);
+}
+
+hipError_t launch_bm_thresholds(const BmParams &p, const int32_t *thr_in, int32_t *thr_out, int init, hipStream_t st) {
+  if (p.nq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bm_thresholds_kernel, dim3((p.nq + 255) / 256), dim3(256), 0, st, p, thr_in, thr_out, init);
+  return hipGetLastError();
+}
+
 hipError_t launch_bm_boot(const BmParams &p, int64_t n_rows, hipStream_t st) {
   if (p.nq <= 0) return hipSuccess;
   (void)n_rows;

@@ -98,6 +98,17 @@ constexpr int BM_BOOT_MIN_UNITS = 24;
 
 } // namespace
 
+struct StagedState {
+  bool open = false;
+  vaq::BmParams bp;
+  vaq::ScanParams sp;
+  struct { int chunk, n, cap, qb, units; } bi;
+  int k = 0, defer_cap = 0, nr = 0, r_next = 0;
+  int limits[4] = {0, 0, 0, 0};
+  int32_t *labels = nullptr;
+  float *dist = nullptr;
+};
+
 struct vaqhip_index {
   int D = 0, M = 0, L = 0;
   int max_bits = 0, min_bits = 0, total_bits = 0, W = 0, layout = 0, lut_floats = 0;
@@ -130,6 +141,7 @@ struct vaqhip_index {
   // option "exact_ties": original row -> bucketed row (built at the first such search after the codes change),
   // the scan's k + 1 results, the replay list
   DevBuf d_inv, d_rowbucket, w_ex_labels, w_ex_dist, w_ex_list;
+  StagedState staged;  // vaqhip_search_begin_device .. vaqhip_search_finish_device
   bool inv_valid = false;
   hipStream_t stream = nullptr;
   // The workspaces above are shared by every call on this index.  Host-side enqueues are
@@ -465,10 +477,86 @@ int ensure_events(vaqhip_index *ix) {
   return VAQHIP_OK;
 }
 
+// ---- bucket-major rounds (vaq_scan_bm.hip): helpers shared by the one-call search and the staged one ----
+struct BmRoundInfo {
+  int chunk, n, cap, qb, units;
+};
+
+// rounds [r0, r1) of nr: plan, scan, select
+int bm_run_rounds(vaqhip_index *ix, vaq::BmParams &bp, const int *limits, int r0, int r1, int nr, const BmRoundInfo &bi,
+                  hipStream_t st) {
+  for (int r = r0; r < r1; r++) {
+    bp.retry = r + 1 < nr ? 1 : 0;
+    bp.limit = limits[r];
+    bp.init64 = r == 0 ? 1 : 0;
+    HIP_TRY(vaq::launch_bm_plan(bp, st));
+    HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
+    HIP_TRY(vaq::launch_bm_select(bp, st));
+    if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what the round planned and appended
+      const int chunk = bi.chunk, n = bi.n;
+      std::vector<unsigned> hq((size_t)3 * chunk);
+      std::vector<int> hcnt((size_t)ix->n_buckets);
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipMemcpy(hq.data(), ix->w_bm_query.p, hq.size() * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hcnt.data(), bp.cnt, hcnt.size() * 4, hipMemcpyDeviceToHost));
+      unsigned long long handed = 0, appended = 0, over = 0, maxc = 0, pairs = 0, groups = 0, work = 0;
+      for (int i = 0; i < n; i++) {
+        if (hq[i] != 0xffffffffu) handed++;
+        const unsigned c = hq[(size_t)chunk + i];
+        appended += c;
+        over += c > (unsigned)bi.cap;
+        maxc = std::max<unsigned long long>(maxc, c);
+      }
+      std::vector<int> hb((size_t)ix->n_buckets + 1);
+      HIP_TRY(hipMemcpy(hb.data(), ix->d_bstart.p, hb.size() * 4, hipMemcpyDeviceToHost));
+      for (int b = 0; b < ix->n_buckets; b++) {
+        pairs += hcnt[b];
+        const unsigned long long g = (hcnt[b] + bi.qb - 1) / bi.qb;
+        groups += g;
+        work += g * (unsigned long long)(hb[b + 1] - hb[b]);
+      }
+      std::fprintf(stderr, "[VAQHIP_BM_DEBUG] round %d (limit %d): queries %d still open after it %llu; (query, bucket) pairs %llu, items %llu, row-steps x QB "
+                           "%.3e (= %.2f %% of rows per query slot); candidates appended %llu (max %llu per query), overflowed "
+                           "queries %llu; pass A units %d\n",
+                   r, limits[r], n, handed, pairs, groups, (double)work * bi.qb, 100.0 * (double)work * bi.qb / ((double)n * (double)ix->N),
+                   appended, maxc, over, bi.units);
+    }
+  }
+  return VAQHIP_OK;
+}
+
+// what the expensive / overflowed queries have left: the best-first form's second launch, DEFER_SLICES
+// workgroups per listed query (those beyond the list's length return at once), merged into the results
+int bm_fallback(vaqhip_index *ix, const vaq::ScanParams &sp, int defer_cap, int k, int32_t *labels, float *dist,
+                hipStream_t st) {
+  vaq::ScanParams s2 = sp;
+  s2.defer_units = 0;
+  s2.defer_mode = 1;
+  s2.bm_done = nullptr;
+  s2.qorder = nullptr;
+  s2.nq = defer_cap;
+  s2.n_slices = DEFER_SLICES;
+  const int step2 = vaq::scan_wg_step_rows(ix->layout, ix->M);
+  int64_t rows2 = (ix->N + DEFER_SLICES - 1) / DEFER_SLICES;
+  rows2 = std::max<int64_t>(step2, ((rows2 + step2 - 1) / step2) * step2);
+  s2.slice_rows = rows2;
+  s2.slice_stride = rows2;
+  s2.share_thr = 1;
+  s2.final_labels = nullptr;
+  s2.final_dist = nullptr;
+  int grid2 = 0;
+  HIP_TRY(vaq::launch_scan(s2, &grid2, st));
+  HIP_TRY(vaq::launch_defer_merge(sp.defer_count, defer_cap, sp.defer_list, DEFER_SLICES, k, sp.part_d, sp.part_id,
+                                  sp.part_cnt, ix->id_base, labels, dist, st));
+  return VAQHIP_OK;
+}
+
 // core: device pointers in, device pointers out, enqueue only
 int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
-                int32_t *d_labels, float *d_dist, hipStream_t st) {
+                int32_t *d_labels, float *d_dist, hipStream_t st, int32_t *stage_thr_out = nullptr) {
   if (ix->N < 0) return fail(VAQHIP_ESTATE, "search before codes were set");
+  if (ix->staged.open)
+    return fail(VAQHIP_ESTATE, "a staged search is open on this index: call vaqhip_search_finish_device first");
   if (((ix->methods & VAQHIP_METHOD_TI) != 0) != (ix->ti_T > 0))
     return fail(VAQHIP_ESTATE, ix->ti_T > 0 ? "the rows are grouped by TI cluster: the method must include TI"
                                              : "method TI needs vaqhip_index_set_ti_clusters first");
@@ -499,6 +587,12 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
     if (rc) return rc;
   }
   const int chunk = std::min(nq, QUERY_CHUNK);
+  if (stage_thr_out) {
+    if (!(pl.bm && pl.bf && pl.n_slices == 1 && ix->N > 0 && nq <= QUERY_CHUNK && !ti))
+      return fail(VAQHIP_EUNSUPPORTED, "a staged search needs the bucket-major rounds (streamed byte codes, >= 8 queries, "
+                                       "at most %d per call)", QUERY_CHUNK);
+    timing = false;
+  }
   // (BitVecEngine::queryLUT projects with checking, BitVecEngine.hpp:1226: non-finite coordinates -> 0,
   //  which needs a pass over the queries even without a rotation)
   const bool do_project = !projected && (ix->has_eig || ix->seq);
@@ -821,65 +915,37 @@ int search_core(vaqhip_index *ix, const float *d_queries, int nq, int k, int pro
       if (ix->opt_bm_round > 0) limits[nr++] = ix->opt_bm_round;
       limits[nr++] = 0;
       limits[nr++] = 0;
-      for (int r = 0; r < nr; r++) {
-        bp.retry = r + 1 < nr ? 1 : 0;
-        bp.limit = limits[r];
-        bp.init64 = r == 0 ? 1 : 0;
-        HIP_TRY(vaq::launch_bm_plan(bp, st));
-        HIP_TRY(vaq::launch_scan_bm(bp, ix->n_cu, st));
-        HIP_TRY(vaq::launch_bm_select(bp, st));
-        if (getenv("VAQHIP_BM_DEBUG")) {  // diagnostic (synchronises): what pass A handed over and what pass B appended
-        std::vector<unsigned> hq((size_t)3 * chunk), hthr((size_t)n);
-        std::vector<int> hcnt((size_t)ix->n_buckets);
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(hq.data(), ix->w_bm_query.p, hq.size() * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hcnt.data(), bp.cnt, hcnt.size() * 4, hipMemcpyDeviceToHost));
-        unsigned long long handed = 0, appended = 0, over = 0, maxc = 0, pairs = 0, groups = 0, work = 0;
-        for (int i = 0; i < n; i++) {
-          if (hq[i] != 0xffffffffu) handed++;
-          const unsigned c = hq[(size_t)chunk + i];
-          appended += c;
-          over += c > (unsigned)pl.bm_cap;
-          maxc = std::max<unsigned long long>(maxc, c);
-        }
-        std::vector<int> hb((size_t)ix->n_buckets + 1);
-        HIP_TRY(hipMemcpy(hb.data(), ix->d_bstart.p, hb.size() * 4, hipMemcpyDeviceToHost));
-        for (int b = 0; b < ix->n_buckets; b++) {
-          pairs += hcnt[b];
-          const unsigned long long g = (hcnt[b] + pl.bm_qb - 1) / pl.bm_qb;
-          groups += g;
-          work += g * (unsigned long long)(hb[b + 1] - hb[b]);
-        }
-        std::fprintf(stderr, "[VAQHIP_BM_DEBUG] round %d (limit %d): queries %d still open after it %llu; (query, bucket) pairs %llu, items %llu, row-steps x QB "
-                             "%.3e (= %.2f %% of rows per query slot); candidates appended %llu (max %llu per query), overflowed "
-                             "queries %llu; pass A units %d\n",
-                     r, limits[r], n, handed, pairs, groups, (double)work * pl.bm_qb, 100.0 * (double)work * pl.bm_qb / ((double)n * (double)ix->N),
-                     appended, maxc, over, pl.defer_units);
+      const BmRoundInfo bi = {chunk, n, pl.bm_cap, pl.bm_qb, pl.defer_units};
+      if (stage_thr_out) {
+        // staged search (vaqhip_search_begin_device): the limited rounds now; the thresholds they leave go
+        // to the caller, who exchanges them with the other shards; vaqhip_search_finish_device goes on
+        int r_split = 0;
+        while (r_split < nr && limits[r_split] > 0) r_split++;
+        int rc = bm_run_rounds(ix, bp, limits, 0, r_split, nr, bi, st);
+        if (rc) return rc;
+        // (no limited round in this plan: the 64-bit words still have to be made from g_thr)
+        HIP_TRY(vaq::launch_bm_thresholds(bp, nullptr, stage_thr_out, r_split == 0 ? 1 : 0, st));
+        StagedState &ss = ix->staged;
+        ss.open = true;
+        ss.bp = bp;
+        ss.sp = sp;
+        ss.bi.chunk = bi.chunk; ss.bi.n = bi.n; ss.bi.cap = bi.cap; ss.bi.qb = bi.qb; ss.bi.units = bi.units;
+        ss.k = k;
+        ss.defer_cap = defer_cap;
+        ss.nr = nr;
+        ss.r_next = r_split;
+        for (int r = 0; r < 4; r++) ss.limits[r] = limits[r];
+        ss.labels = d_labels;
+        ss.dist = d_dist;
+        ix->last = tm;
+        return ws_release(ix, st);
       }
-      }
+      int rc = bm_run_rounds(ix, bp, limits, 0, nr, nr, bi, st);
+      if (rc) return rc;
     }
     if (defer || bm) {
-      // second launch: what the expensive queries have left, DEFER_SLICES workgroups each (those
-      // beyond the list's length return at once), then their lists are merged into the results
-      vaq::ScanParams s2 = sp;
-      s2.defer_units = 0;
-      s2.defer_mode = 1;
-      s2.bm_done = nullptr;
-      s2.qorder = nullptr;
-      s2.nq = defer_cap;
-      s2.n_slices = DEFER_SLICES;
-      const int step2 = vaq::scan_wg_step_rows(ix->layout, ix->M);
-      int64_t rows2 = (ix->N + DEFER_SLICES - 1) / DEFER_SLICES;
-      rows2 = std::max<int64_t>(step2, ((rows2 + step2 - 1) / step2) * step2);
-      s2.slice_rows = rows2;
-      s2.slice_stride = rows2;
-      s2.share_thr = 1;
-      s2.final_labels = nullptr;
-      s2.final_dist = nullptr;
-      int grid2 = 0;
-      HIP_TRY(vaq::launch_scan(s2, &grid2, st));
-      HIP_TRY(vaq::launch_defer_merge(sp.defer_count, defer_cap, sp.defer_list, DEFER_SLICES, k, sp.part_d, sp.part_id,
-                                      sp.part_cnt, ix->id_base, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st));
+      int rc = bm_fallback(ix, sp, defer_cap, k, d_labels + (size_t)q0 * k, d_dist + (size_t)q0 * k, st);
+      if (rc) return rc;
     }
 #ifdef VAQ_PHASES
     if (pl.bf) {
@@ -973,6 +1039,24 @@ int search_device_locked(vaqhip_index *ix, const float *d_queries, int nq, int k
     if (rc) return rc;
   }
   return VAQHIP_OK;
+}
+
+// second half of a staged search: take over the exchanged thresholds, the remaining rounds, the fallback
+int search_finish_locked(vaqhip_index *ix, const int32_t *d_thr_in, hipStream_t st) {
+  StagedState &ss = ix->staged;
+  if (!ss.open) return fail(VAQHIP_ESTATE, "no staged search is open on this index");
+  {
+    int rc = ws_acquire(ix, st);
+    if (rc) return rc;
+  }
+  ss.open = false;
+  if (d_thr_in) HIP_TRY(vaq::launch_bm_thresholds(ss.bp, d_thr_in, nullptr, 0, st));
+  const BmRoundInfo bi = {ss.bi.chunk, ss.bi.n, ss.bi.cap, ss.bi.qb, ss.bi.units};
+  int rc = bm_run_rounds(ix, ss.bp, ss.limits, ss.r_next, ss.nr, ss.nr, bi, st);
+  if (rc) return rc;
+  rc = bm_fallback(ix, ss.sp, ss.defer_cap, ss.k, ss.labels, ss.dist, st);
+  if (rc) return rc;
+  return ws_release(ix, st);
 }
 
 } // namespace
@@ -1358,6 +1442,35 @@ int vaqhip_index_set_codes_u16(vaqhip_index *ix, const uint16_t *codes, int64_t 
 int vaqhip_index_set_codes_u16_device(vaqhip_index *ix, const uint16_t *d_codes, int64_t N,
                                       int64_t id_base, void *stream) {
   return set_codes_common(ix, d_codes, true, N, id_base, static_cast<hipStream_t>(stream));
+}
+
+int vaqhip_search_staged_supported(vaqhip_index *ix, int nq, int k) {
+  if (!ix || nq <= 0 || k <= 0 || k > VAQHIP_MAX_K) return 0;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  if (ix->N <= 0 || ix->ti_T > 0 || nq > QUERY_CHUNK || ix->opt_exact) return 0;
+  Plan pl;
+  if (make_plan(ix, nq, k, &pl)) return 0;
+  return (pl.bm && pl.bf && pl.n_slices == 1) ? 1 : 0;
+}
+
+int vaqhip_search_begin_device(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,
+                               int32_t *d_labels, float *d_distances, int32_t *d_thresholds_out, void *stream) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  if (!d_thresholds_out) return fail(VAQHIP_EINVAL, "null pointer");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  if (ix->opt_exact) return fail(VAQHIP_EUNSUPPORTED, "exact_ties is a property of ONE index; shards merge by (distance, label)");
+  return search_core(ix, d_queries, nq, k, projected, d_labels, d_distances, static_cast<hipStream_t>(stream),
+                     d_thresholds_out);
+}
+
+int vaqhip_search_finish_device(vaqhip_index *ix, const int32_t *d_thresholds_in, void *stream) {
+  if (!ix) return fail(VAQHIP_EINVAL, "index is null");
+  std::lock_guard<std::mutex> lk(ix->mu);
+  DeviceGuard g(ix->device);
+  if (!g.ok) return fail(VAQHIP_ENODEVICE, "hipSetDevice(%d) failed", ix->device);
+  return search_finish_locked(ix, d_thresholds_in, static_cast<hipStream_t>(stream));
 }
 
 int vaqhip_search_device(vaqhip_index *ix, const float *d_queries, int nq, int k, int projected,

@@ -351,6 +351,35 @@ class VaqHip:
             C.c_void_p(labels.data_ptr()), C.c_void_p(dists.data_ptr()), C.c_void_p(st)))
         return labels, dists
 
+    # ----------------------------------------------- staged search (sharded hosts) --
+    def staged_supported(self, nq: int, k: int) -> bool:
+        """vaqhip_search_staged_supported: would a search of nq queries run the bucket-major rounds,
+        i.e. can it be split around a threshold exchange between shards?"""
+        self._ensure_codes()
+        return bool(_lib.load().vaqhip_search_staged_supported(self._h, int(nq), int(k)))
+
+    def search_begin_device(self, d_queries, k: int, out, thr_out, projected: bool = False) -> None:
+        """vaqhip_search_begin_device: first rounds; thr_out (int32 [nq], CUDA) receives the thresholds
+        (distance bits) to be MIN-reduced over the shards; out = (labels, dists) as for search_device."""
+        import torch
+        self._ensure_codes()
+        q = d_queries.contiguous()
+        labels, dists = out
+        nq = q.shape[0]
+        assert thr_out.is_cuda and thr_out.dtype == torch.int32 and thr_out.numel() == nq and thr_out.is_contiguous()
+        st = torch.cuda.current_stream(q.device).cuda_stream
+        _lib.check(_lib.load().vaqhip_search_begin_device(
+            self._h, C.c_void_p(q.data_ptr()), nq, k, 1 if projected else 0, C.c_void_p(labels.data_ptr()),
+            C.c_void_p(dists.data_ptr()), C.c_void_p(thr_out.data_ptr()), C.c_void_p(st)))
+
+    def search_finish_device(self, thr_in=None) -> None:
+        """vaqhip_search_finish_device: the rest of the search under the exchanged thresholds."""
+        import torch
+        dev = thr_in.device if thr_in is not None else torch.device("cuda", self.device)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.load().vaqhip_search_finish_device(
+            self._h, C.c_void_p(thr_in.data_ptr()) if thr_in is not None else None, C.c_void_p(st)))
+
     # ----------------------------------------------------- encode / refine --
     def encode(self, XTrain: np.ndarray, projected: bool = True) -> None:
         """VAQ::encode (VAQ.cpp:663-748): fills mCodebook (N x M uint16).  Like

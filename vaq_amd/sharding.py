@@ -139,3 +139,42 @@ def all_gather_packed(packed_local, gathered, group=None):
     import torch.distributed as dist
     dist.all_gather_into_tensor(gathered.view(-1), packed_local.view(-1), group=group)
     return gathered
+
+
+# ---------------------------------------------------------------------------
+# Threshold exchange (round 3).  Every shard finds ITS k best, so its admission thresholds are
+# looser than the global k-th distance allows.  With the staged search of the C ABI
+# (vaqhip_search_begin_device / _finish_device) each rank runs the first rounds -- every query's
+# nearest buckets of its shard --, ONE all-reduce(MIN) of nq int32 words (distance bit patterns:
+# ordered like the distances) gives every rank the tightest bound any shard has found, and the rest
+# of each shard is scanned under it.  A shard may then return fewer than k rows for a query; the
+# merge of the gathered lists is unchanged and equals the single-index result bit for bit.
+# ---------------------------------------------------------------------------
+def staged_agreed(index, nq: int, k: int, group=None) -> bool:
+    """All ranks must take the same path (there is a collective inside): MIN over the ranks of
+    "my index can split this search"."""
+    import torch
+    import torch.distributed as dist
+    ok = 1 if index.staged_supported(nq, k) else 0
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    dev = torch.device("cuda", index.device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def search_staged(index, d_queries, k: int, out, thr, group=None, host_bounce: bool = False):
+    """begin -> all-reduce(MIN) of the thresholds -> finish.  thr: int32 [nq] CUDA scratch.
+    host_bounce: the backend cannot reduce CUDA tensors (gloo rehearsals): go through the host."""
+    import torch.distributed as dist
+    index.search_begin_device(d_queries, k, out, thr)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if host_bounce:
+            h = thr.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+            thr.copy_(h)
+        else:
+            dist.all_reduce(thr, op=dist.ReduceOp.MIN, group=group)
+    index.search_finish_device(thr)
+    return out
