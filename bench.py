@@ -97,9 +97,11 @@ def parse():
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "queries"],
                     help="multi-GPU: shard code rows (all-gather + merge; default), or replicate codes and shard queries")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
-    ap.add_argument("--exchange-thresholds", type=int, default=1,
-                    help="rows mode, N > 1: all-reduce(MIN) the per-query thresholds between the first rounds and the rest "
-                         "of the search (0: every shard on its own)")
+    ap.add_argument("--exchange-thresholds", type=int, default=0,
+                    help="rows mode, N > 1: 1 = all-reduce(MIN) the per-query thresholds between the first rounds and the rest "
+                         "of the search (the staged search of the C ABI).  Off by default: measured on 8 shards of a 250M-row "
+                         "cut it saves 1.6 %% of the shards' scan time (tools/exp_threshold_exchange.py) -- the first rounds "
+                         "already leave every shard close to its final thresholds -- against one more collective per step")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo; RCCL refuses duplicate GPUs)")
     return ap.parse_args()

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--skip-base", action="store_true", help="do not time the one-workgroup-per-query form")
     ap.add_argument("--units", default="", help="comma-separated bm_units values to time (instead of the default shape)")
     ap.add_argument("--rounds", default="", help="comma-separated bm_boot:bm_round pairs to time")
+    ap.add_argument("--bucket-bits", type=int, default=0)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -37,7 +38,8 @@ def main():
     build.build_lib()
     bits = [8] * a.m
     t0 = time.time()
-    v, _, _, _ = bench.build_index(bits, a.rows, 0, a.rows, dev, 0, 1, 0, iters=8, random_codes=a.random_codes)
+    v, _, _, _ = bench.build_index(bits, a.rows, 0, a.rows, dev, 0, 1, 0, iters=8, random_codes=a.random_codes,
+                                   bucket_bits=a.bucket_bits)
     print(f"index of {a.rows} rows built in {time.time() - t0:.1f}s: {v.info()}", flush=True)
     queries = harness.sift_like(a.nq, 128, stream=7, device=dev)
     k = a.k
