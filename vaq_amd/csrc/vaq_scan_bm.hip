@@ -424,9 +424,16 @@ template <int QB> struct BmVec;
 template <> struct BmVec<2> { typedef f32x2 T; };
 template <> struct BmVec<4> { typedef f32x4 T; };
 
+// candidates a wave gathers before it appends them (each append is a returning memory-side atomic the wave
+// has to wait for: gathered, one wait serves a batch)
+#ifndef VAQ_BM_BATCH
+#define VAQ_BM_BATCH 24
+#endif
+constexpr int BM_BATCH = VAQ_BM_BATCH;
+constexpr int BM_CB_CAP = BM_BATCH - 1 + 64;  // one finishing pass adds at most 64
 __host__ __device__ inline size_t bm_lds_bytes(int M, int qb, int nwaves) {
   const int qcw = M <= 16 ? M / 4 - 1 : 0;
-  return (size_t)M * 256 * qb * 4 + (size_t)nwaves * BM_QCAP * 4 * (3 + qcw);
+  return (size_t)M * 256 * qb * 4 + (size_t)nwaves * (BM_QCAP * 4 * (3 + qcw) + BM_CB_CAP * 12);
 }
 
 constexpr int BM_MAX_RUNS = 256;  // second codes of a bucket (bucket_t == 0: all 256)
@@ -454,11 +461,14 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   float *lut = reinterpret_cast<float *>(smem);  // entry (t * 256 + c) of query i at (t * 256 + c) * QB + i
-  unsigned char *wb = smem + (size_t)M * 256 * QB * 4 + (size_t)wave * BM_QCAP * 4 * (3 + QCW);
+  unsigned char *wb = smem + (size_t)M * 256 * QB * 4 + (size_t)wave * (BM_QCAP * 4 * (3 + QCW) + BM_CB_CAP * 12);
   int *q_row = reinterpret_cast<int *>(wb);
   float *q_part = reinterpret_cast<float *>(q_row + BM_QCAP);
   int *q_i = reinterpret_cast<int *>(q_part + BM_QCAP);
   uint32_t *q_cw = reinterpret_cast<uint32_t *>(q_i + BM_QCAP);
+  float *cb_d = reinterpret_cast<float *>(q_cw + (size_t)QCW * BM_QCAP);  // gathered candidates: distance, row, slot
+  int *cb_row = reinterpret_cast<int *>(cb_d + BM_CB_CAP);
+  int *cb_i = cb_row + BM_CB_CAP;
   const int K0 = p.n_buckets, bt = p.bucket_t, k = p.k;
   const uint32_t *__restrict__ codes = p.codes;
   const uint32_t *__restrict__ perm = p.perm;
@@ -551,7 +561,8 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         const float4 *g4[QB];
 #pragma unroll
         for (int i = 0; i < QB; i++) g4[i] = reinterpret_cast<const float4 *>(p.lut + (size_t)qi[i] * p.lut_floats);
-        for (int e4 = tid; e4 < M * 64; e4 += nthreads) {
+        // (SUB: the first two tables are never gathered -- their sum per run is already in s_p01)
+        for (int e4 = tid + (SUB ? 128 : 0); e4 < M * 64; e4 += nthreads) {
           float4 v[QB];
 #pragma unroll
           for (int i = 0; i < QB; i++) v[i] = g4[i][e4];
@@ -577,9 +588,9 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
 #pragma unroll
       for (int i = 0; i < QB; i++) {
         thr[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)s_thr[i]));
-        l0[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[(size_t)(b >> bt) * QB + i])));
+        l0[i] = SUB ? 0.0f : bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(lut[(size_t)(b >> bt) * QB + i])));
       }
-      int qcnt = 0;
+      int qcnt = 0, ccnt = 0;
 
       auto pick_q = [&](const int i) -> int { return s_q[i]; };
       auto pick_thr = [&](const int i) -> float {
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         }
       };
 
-      // a row whose complete sum is not above its query's threshold: one more candidate of that query
+      // up to 64 gathered candidates -> their queries' buffers
       auto append = [&](const float d, const int row, const int i, const bool ok) {
         if (__ballot(ok) == 0ull) return;
         int q = 0;
@@ -662,6 +673,19 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         }
       };
 
+      auto flush = [&]() {
+        while (ccnt > 0) {
+          const int n = ccnt < 64 ? ccnt : 64;
+          ccnt -= n;
+          const bool has = lane < n;
+          const int slot = ccnt + (has ? lane : 0);
+          const float d = cb_d[slot];
+          const int ii = cb_i[slot];
+          // (the threshold may have moved since the row was gathered)
+          append(d, cb_row[slot], ii, has && d <= pick_thr(ii));
+        }
+      };
+
       // phase B: the top n (<= 64) queue entries, one per lane: groups 1.. of the row, abandoning
       // after each (VAQ.cpp:1708)
       auto drain = [&](const int n) {
@@ -688,7 +712,18 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
             alive = acc <= tl;
           }
         }
-        append(acc, row, i, alive);
+        // a row whose complete sum is not above its query's threshold: gathered (no memory access yet)
+        const unsigned long long m = __ballot(alive);
+        if (m != 0ull) {
+          const int pos = ccnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (alive) {
+            cb_d[pos] = acc;
+            cb_row[pos] = row;
+            cb_i[pos] = i;
+          }
+          ccnt += __popcll(m);
+          if (ccnt >= BM_BATCH) flush();
+        }
       };
 
       // rows [rs, re) of the step's item at `base`; p01 (SUB): l0 + l1 of the run, per query
@@ -810,6 +845,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
           if (kk + u < nmine) do_step(ring[u], kk + u);
       }
       while (qcnt > 0) drain(qcnt < 64 ? qcnt : 64);
+      flush();  // (the slots of a candidate are this item's: nothing may stay gathered)
     }
   }
 }
