@@ -459,7 +459,9 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   __shared__ int s_run_s[SUB ? BM_MAX_RUNS : 1], s_run_e[SUB ? BM_MAX_RUNS : 1], s_cum[SUB ? BM_MAX_RUNS + 1 : 1];
   __shared__ float s_p01[SUB ? BM_MAX_RUNS * QB : 1];
   const int tid = threadIdx.x, nthreads = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  // (the wave number through readfirstlane: the compiler then keeps everything derived from it -- step
+  //  numbers, run cursors, row ranges -- in scalar registers instead of comparing vectors under EXEC masks)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
   float *lut = reinterpret_cast<float *>(smem);  // entry (t * 256 + c) of query i at (t * 256 + c) * QB + i
   unsigned char *wb = smem + (size_t)M * 256 * QB * 4 + (size_t)wave * (BM_QCAP * 4 * (3 + QCW) + BM_CB_CAP * 12);
   int *q_row = reinterpret_cast<int *>(wb);
@@ -803,28 +805,46 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         const int base00 = bs & ~(WSTEP - 1);
         // step number -> first row of its item (SUB: through the prefix of the live runs' steps; the
         // cursor only moves forward) [+ the run's rows and l0 + l1]
-        auto step_base = [&](const int kk, int &cursor) -> int {
+        // A cursor keeps its run's step range and first item row in scalar registers: a step inside the
+        // range costs one scalar compare and no LDS access (runs are tens to hundreds of steps long and a
+        // wave takes every 16th step); only when a step leaves the range is the prefix walked on.
+        struct Cursor {
+          int run, lo, hi, row0;  // steps [lo, hi) belong to `run`, whose first item starts at row0
+        };
+        auto seek = [&](Cursor &c, const int sidx) {
+          if (sidx < c.hi) return;  // (wave-uniform: the values come from readfirstlane)
+          int r = c.run, hi = c.hi;
+          do {
+            r++;
+            hi = __builtin_amdgcn_readfirstlane(s_cum[r + 1]);
+          } while (hi <= sidx);
+          c.run = r;
+          c.hi = hi;
+          c.lo = __builtin_amdgcn_readfirstlane(s_cum[r]);
+          c.row0 = __builtin_amdgcn_readfirstlane(s_run_s[r]) & ~(WSTEP - 1);
+        };
+        auto step_base = [&](const int kk, Cursor &c) -> int {
           const int kc = kk < nmine - 1 ? kk : nmine - 1;
           const int sidx = wave + kc * nwaves;
           if (!SUB) return base00 + sidx * WSTEP;
-          while (__builtin_amdgcn_readfirstlane(s_cum[cursor + 1]) <= sidx) cursor++;
-          return (__builtin_amdgcn_readfirstlane(s_run_s[cursor]) & ~(WSTEP - 1)) +
-                 (sidx - __builtin_amdgcn_readfirstlane(s_cum[cursor])) * WSTEP;
+          seek(c, sidx);
+          return c.row0 + (sidx - c.lo) * WSTEP;
         };
-        int cur_l = 0, cur_p = 0, run_p = -1;  // cursors of the loads (ahead) and of the steps; run whose data is cached
+        Cursor cur_l = {-1, 0, 0, 0}, cur_p = {-1, 0, 0, 0};  // of the loads (ahead) and of the steps
+        int run_p = -1;                                           // run whose rows and l0 + l1 are cached
         int rs = bs, re = be;
         float p01[QB];
 #pragma unroll
         for (int i = 0; i < QB; i++) p01[i] = 0.0f;
         auto do_step = [&](const Item &it, const int kk) {
           const int base = step_base(kk, cur_p);
-          if (SUB && cur_p != run_p) {
-            run_p = cur_p;
-            rs = __builtin_amdgcn_readfirstlane(s_run_s[cur_p]);
-            re = __builtin_amdgcn_readfirstlane(s_run_e[cur_p]);
+          if (SUB && cur_p.run != run_p) {
+            run_p = cur_p.run;
+            rs = __builtin_amdgcn_readfirstlane(s_run_s[run_p]);
+            re = __builtin_amdgcn_readfirstlane(s_run_e[run_p]);
 #pragma unroll
             for (int i = 0; i < QB; i++)
-              p01[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(s_p01[cur_p * QB + i])));
+              p01[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(s_p01[run_p * QB + i])));
           }
           step(it, kk, base, rs, re, p01);
         };
