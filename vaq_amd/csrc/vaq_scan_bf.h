@@ -427,7 +427,13 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
   constexpr int SEG_ROWS = BF_SEG_STEPS * WSTEP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthreads = blockDim.x;
+#ifdef VAQ_BF_VECTOR_WAVE
   const int lane = tid & 63, wave = tid >> 6;
+#else
+  // (through readfirstlane: what is derived from the wave number -- its buffers' addresses, its share of the
+  //  bootstrap, `wave == 0` tests -- is then scalar for the compiler)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int total = p.nq * p.n_slices;
   // One workgroup per query on a cache-resident database: nothing is gained by giving an XCD a
   // contiguous range of queries (C2 without the ranking: 0.74 ms; block b -> query b: 0.69 ms); with

@@ -729,13 +729,20 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
       };
 
       // rows [rs, re) of the step's item at `base`; p01 (SUB): l0 + l1 of the run, per query
-      auto step = [&](const Item &cur, const int kstep, const int base, const int rs, const int re, const float *p01) {
+      // (SUB) is the cached run out of every query's reach?  Re-evaluated only when the run or the
+      // thresholds change -- comparing two scalar floats takes vector instructions on this ISA
+      bool run_dead = false;
+      auto step = [&](const Item &cur, const int kstep, const int base, const int rs, const int re, const float *p01,
+                      const bool run_changed) {
         refresh(kstep);
         if (SUB) {  // the run may have dropped out of reach since the item began
-          bool dead = true;
+          if (run_changed || (kstep & (BM_THR_EVERY - 1)) == 0) {
+            bool dead = true;
 #pragma unroll
-          for (int i = 0; i < QB; i++) dead = dead && !(p01[i] <= thr[i]);
-          if (dead) return;
+            for (int i = 0; i < QB; i++) dead = dead && !(p01[i] <= thr[i]);
+            run_dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;
+          }
+          if (run_dead) return;
         }
         const bool interior = base >= rs && base + WSTEP <= re;  // wave-uniform
 #pragma unroll
@@ -750,10 +757,14 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
             // dism (= l0 + l1, the run's) += l2; dism += l3 -> the first group's sum
             const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
             const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
+            VT pv;  // (element-wise vector adds: the packed fp32 add does two of them per instruction)
+#pragma unroll
+            for (int i = 0; i < QB; i++) pv[i] = p01[i];
+            pv = pv + v2;
+            pv = pv + v3;
 #pragma unroll
             for (int i = 0; i < QB; i++) {
-              part[i] = p01[i] + v2[i];
-              part[i] = part[i] + v3[i];
+              part[i] = pv[i];
               alive[i] = in_range && part[i] <= thr[i];
               any = any || alive[i];
             }
@@ -838,7 +849,8 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         for (int i = 0; i < QB; i++) p01[i] = 0.0f;
         auto do_step = [&](const Item &it, const int kk) {
           const int base = step_base(kk, cur_p);
-          if (SUB && cur_p.run != run_p) {
+          const bool run_changed = SUB && cur_p.run != run_p;
+          if (run_changed) {
             run_p = cur_p.run;
             rs = __builtin_amdgcn_readfirstlane(s_run_s[run_p]);
             re = __builtin_amdgcn_readfirstlane(s_run_e[run_p]);
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
             for (int i = 0; i < QB; i++)
               p01[i] = bits_to_float((unsigned)__builtin_amdgcn_readfirstlane((int)float_to_bits(s_p01[run_p * QB + i])));
           }
-          step(it, kk, base, rs, re, p01);
+          step(it, kk, base, rs, re, p01, run_changed);
         };
         Item ring[BM_RING];
 #pragma unroll
