@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--ti", default="", help="T[,seg]: triangle-inequality form with T clusters over the first "
                                              "seg subspaces (default all), method EA_TI (not the headline metric)")
     ap.add_argument("--visit", type=float, default=1.0, help="--visit-cluster of demo_vaq (with --ti)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="any vaqhip_set_option key (experiments), e.g. --set fused_front=0")
     ap.add_argument("--no-skip", action="store_true", help="visit every bucket (streaming-rate measurement)")
     ap.add_argument("--bucket-bits", type=int, default=0, help="bits of the first code that key the row buckets (0 = auto)")
     ap.add_argument("--random-codes", action="store_true", help="uniform-random codes instead of encoded vectors")
@@ -503,6 +505,9 @@ def main():
         v.set_option("defer_units", args.defer)
     if args.cost_order >= 0:
         v.set_option("cost_order", args.cost_order)
+    for kv in args.set:
+        key, _, val = kv.partition("=")
+        v.set_option(key, int(val))
     info = v.info()
 
     # every buffer of the steady-state loop is allocated once, here; with several ranks the

@@ -129,6 +129,35 @@ __device__ __forceinline__ SelView sel_view(unsigned char *base, int kp, int cca
 __device__ __forceinline__ float bits_to_float(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ unsigned float_to_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 
+// Byte B of a code dword, times 1 << SH (the byte offset of its lookup-table entry), in ONE vector
+// instruction: the shifter's operand is selected by byte (SDWA).  The compiler writes v_bfe_u32 +
+// v_lshl_add_u32 for the same value; in the scan loops that was one instruction in five.
+#ifndef VAQ_NO_SDWA
+template <int B, int SH> __device__ __forceinline__ unsigned byte_shl(const unsigned c) {
+  unsigned r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "n"(SH), "v"(c));
+  if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "n"(SH), "v"(c));
+  if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "n"(SH), "v"(c));
+  if (B == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "n"(SH), "v"(c));
+  return r;
+}
+#else
+template <int B, int SH> __device__ __forceinline__ unsigned byte_shl(const unsigned c) { return ((c >> (8 * B)) & 0xffu) << SH; }
+#endif
+// Entry (byte B of c) of the 256-entry float table at LDS byte offset `table`: the address is formed as
+// an INTEGER, so that the table's offset lands in the instruction's immediate field -- through a
+// pointer into the dynamic LDS block the compiler adds the block's (link-time) base with one more
+// instruction per lookup.  The callers' tables start at LDS offset 0 (lds_base_is_zero).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+template <int B> __device__ __forceinline__ float lds_lut(const unsigned table, const unsigned c) {
+  return *reinterpret_cast<lds_cfloat *>((uintptr_t)(byte_shl<B, 2>(c) + table));
+}
+// the kernels that address LDS by integer keep their lookup tables first in the dynamic block and
+// have no static LDS: the block starts at 0.  Checked once per workgroup (a trap, not a wrong answer).
+__device__ __forceinline__ void lds_base_is_zero(const void *dynamic_lds) {
+  if ((unsigned)(uintptr_t)dynamic_lds != 0u) __builtin_trap();
+}
+
 // (The spin is wave-uniform: only lane 0 tries the lock, but every lane goes round the loop.
 //  A spin under `if (lane == 0)` is not a reconvergence point the compiler has to respect --
 //  a prototype with such a spin inside a retry loop had lanes 1..63 run ahead of lane 0.)
@@ -210,6 +239,7 @@ constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 // A CU admits waves by SGPR allocation too: above 80 SGPRs only 6-7 waves fit a
 // SIMD instead of 8 (MI355X_MICROARCH.md, "Residency").  The scan kernels are
 // latency-bound, so cap them and let the compiler keep the overflow in VGPR lanes.
+// (The best-first kernels run seven waves per SIMD by their LDS anyway and take 96: VAQ_BF_SGPRS.)
 #ifndef VAQ_SCAN_SGPR_CAP
 #define VAQ_SCAN_SGPR_CAP 80
 #endif

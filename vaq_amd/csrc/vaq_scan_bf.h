@@ -264,9 +264,21 @@ template <int M> struct BfBytes {
   static constexpr int WPR = Item::WPR;
   static constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
   static constexpr bool HAS_TAIL = WPR > 1;
+  // No test after the first two terms: a byte costs one instruction to take out of its dword, and on the
+  // cache-resident databases this form serves 41 % of the rows of a visited bucket pass that test (C2) --
+  // some lane of nearly every wave step does, so the wave looks the other two terms up anyway and the
+  // test only adds a compare and a branch (C2 0.535 -> 0.517 ms).  The sums are the same sums.
+#ifndef VAQ_BF_BYTES_TEST_A
+#define VAQ_BF_BYTES_TEST_A 0
+#endif
+  static constexpr bool TEST_A = VAQ_BF_BYTES_TEST_A != 0;
   static constexpr int LDS_WORDS = 0;  // no per-workgroup tables besides the LUT
   const float *lut;
-  __device__ __forceinline__ void init(const ScanParams &, const float *lut_lds, unsigned *, int, int) { lut = lut_lds; }
+  // (the tables are addressed by their LDS byte offsets, lds_lut: they must start at offset 0)
+  __device__ __forceinline__ void init(const ScanParams &, const float *lut_lds, unsigned *, int, int) {
+    lut = lut_lds;
+    lds_base_is_zero(lut_lds);
+  }
   __device__ static __forceinline__ int lut_entries(const ScanParams &) { return M * 256; }
   __device__ static __forceinline__ void second_table(const ScanParams &, int &off1, int &ncent1) {
     off1 = 256;
@@ -276,21 +288,21 @@ template <int M> struct BfBytes {
     it.load(codes, (int64_t)(base_row / ROWS) + lane);
   }
   __device__ __forceinline__ float lut4(const uint32_t c4, const int g) const {
-    float dism = lut[(g * 4 + 0) * 256 + (c4 & 0xffu)];
-    dism = dism + lut[(g * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)];
-    dism = dism + lut[(g * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)];
-    dism = dism + lut[(g * 4 + 3) * 256 + (c4 >> 24)];
+    float dism = lds_lut<0>((g * 4 + 0) * 1024, c4);
+    dism = dism + lds_lut<1>((g * 4 + 1) * 1024, c4);
+    dism = dism + lds_lut<2>((g * 4 + 2) * 1024, c4);
+    dism = dism + lds_lut<3>((g * 4 + 3) * 1024, c4);
     return dism;
   }
   template <bool UL0> __device__ __forceinline__ float first_two(const Item &it, const int r, const float l0) const {
     const uint32_t c0 = it.word(r, 0);
-    const float first = UL0 ? l0 : lut[c0 & 0xffu];
-    return first + lut[256 + ((c0 >> 8) & 0xffu)];
+    const float first = UL0 ? l0 : lds_lut<0>(0, c0);
+    return first + lds_lut<1>(1024, c0);
   }
   __device__ __forceinline__ float rest_of_first(const Item &it, const int r, float part) const {
     const uint32_t c0 = it.word(r, 0);
-    part = part + lut[512 + ((c0 >> 16) & 0xffu)];
-    part = part + lut[768 + (c0 >> 24)];
+    part = part + lds_lut<2>(2048, c0);
+    part = part + lds_lut<3>(3072, c0);
     return part;
   }
   __device__ static __forceinline__ uint32_t carry(const Item &it, const int r, const int w) { return it.word(r, w + 1); }
@@ -326,6 +338,7 @@ template <int W, bool CARRY> struct BfBits {
   static constexpr int ROWS = 1;
   static constexpr int QCW = CARRY ? 1 : 0;
   static constexpr bool HAS_TAIL = true;
+  static constexpr bool TEST_A = true;  // (taking a field out of a packed row costs several instructions: C3 0.92 ms with the test, 1.04 without)
   static constexpr int LDS_WORDS = VAQ_BF_MAX_SUBS;  // one packed descriptor per subspace
   const float *lut;
   const unsigned *pd;  // LDS: word | shift << 3 | bits << 8 | lut_off << 12 per subspace
@@ -1112,38 +1125,60 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
         const bool interior = base >= pos && base + WSTEP <= be;  // wave-uniform: no per-row range test
         const int row0 = base + lane * ROWS;
         float part[ROWS];
-        bool alive[ROWS];
-  #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-          part[r] = pol.template first_two<UL0>(cur, r, l0);  // A: dism = l0; dism += l1
-          // (interior is wave-uniform: the row-range test folds into scalar mask logic)
-          const bool in_range = interior || ((row0 + r >= pos) && (row0 + r < be));
-          alive[r] = in_range && !(part[r] > thr_d);
-          STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
-        }
-  #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-          bool live = alive[r];
-          if (live) {  // A2: dism += l2; dism += l3 -> the first group's sum
-            part[r] = pol.rest_of_first(cur, r, part[r]);
-            live = !(part[r] > thr_d);
-          }
+        // a row that survived its first group: to the survivor queue (or, a one-group row, to the candidates)
+        auto keep = [&](const int r, const bool live) {
           STAT_ADD(ST_ALIVE_A2, __popcll(__ballot(live)));
           if (!Pol::HAS_TAIL) {  // (a row of one group ends here)
             gather(part[r], row0 + r, live);
-          } else {
-            const unsigned long long m = __ballot(live);
-            if (m != 0ull) {
-              const int qp = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-              if (live) {
-                q_id[qp] = row0 + r;
-                q_p[qp] = part[r];
+            return;
+          }
+          const unsigned long long m = __ballot(live);
+          if (m == 0ull) return;
+          const int qp = qcnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (live) {
+            q_id[qp] = row0 + r;
+            q_p[qp] = part[r];
   #pragma unroll
-                for (int w = 0; w < QCW; w++) q_cw[w * BF_QCAP + qp] = Pol::carry(cur, r, w);
-              }
-              qcnt += __popcll(m);
-              if (qcnt >= 64) drain(64);
+            for (int w = 0; w < QCW; w++) q_cw[w * BF_QCAP + qp] = Pol::carry(cur, r, w);
+          }
+          qcnt += __popcll(m);
+          if (qcnt >= 64) drain(64);
+        };
+        if (!Pol::TEST_A) {
+          // straight-line: the first group's four terms, one test.  On the steps at a unit's edges the rows
+          // outside it get +inf in place of their sum (never at or below a threshold: thresholds are
+          // finite) -- the wave-uniform branch keeps the range tests off the interior steps, and the
+          // test's mask is the compare's own result
+  #pragma unroll
+          for (int r = 0; r < ROWS; r++) part[r] = pol.rest_of_first(cur, r, pol.template first_two<UL0>(cur, r, l0));
+          if (!interior) {
+  #pragma unroll
+            for (int r = 0; r < ROWS; r++)
+              if (row0 + r < pos || row0 + r >= be) part[r] = INFINITY;
+          }
+  #pragma unroll
+          for (int r = 0; r < ROWS; r++) {
+            STAT_ADD(ST_ALIVE_A, __popcll(__ballot(part[r] < INFINITY)));
+            keep(r, !(part[r] > thr_d));
+          }
+        } else {
+          bool alive[ROWS];
+  #pragma unroll
+          for (int r = 0; r < ROWS; r++) {
+            part[r] = pol.template first_two<UL0>(cur, r, l0);  // A: dism = l0; dism += l1
+            // (interior is wave-uniform: the row-range test folds into scalar mask logic)
+            const bool in_range = interior || ((row0 + r >= pos) && (row0 + r < be));
+            alive[r] = in_range && !(part[r] > thr_d);
+            STAT_ADD(ST_ALIVE_A, __popcll(__ballot(alive[r])));
+          }
+  #pragma unroll
+          for (int r = 0; r < ROWS; r++) {
+            bool live = alive[r];
+            if (live) {  // A2: dism += l2; dism += l3 -> the first group's sum
+              part[r] = pol.rest_of_first(cur, r, part[r]);
+              live = !(part[r] > thr_d);
             }
+            keep(r, live);
           }
         }
       };

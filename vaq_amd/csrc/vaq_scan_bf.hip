@@ -12,13 +12,20 @@ namespace vaq {
 #define VAQ_BF_WAVES_PER_SIMD 7
 #endif
 #define VAQ_BF_VGPR_CAP __attribute__((amdgpu_waves_per_eu(VAQ_BF_WAVES_PER_SIMD, 8)))
+// SGPRs: up to 96 a CU still admits seven 256-thread workgroups (min(8, 800 / (ceil(sgpr / 16) * 16 + 16)),
+// MI355X_MICROARCH.md "Residency") -- as many as the LDS allows here; at 80 the compiler kept ~400 values
+// in VGPR lanes (v_readlane / v_writelane in the scan loop): C2 0.541 -> 0.535 ms, C3 0.93 -> 0.92
+#ifndef VAQ_BF_SGPR_CAP
+#define VAQ_BF_SGPR_CAP 96
+#endif
+#define VAQ_BF_SGPRS __attribute__((amdgpu_num_sgpr(VAQ_BF_SGPR_CAP)))
 template <int M, bool UL0>
-__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS VAQ_BF_VGPR_CAP void scan_bytes_bf_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_BF_SGPRS VAQ_BF_VGPR_CAP void scan_bytes_bf_kernel(ScanParams p) {
   scan_bf_body<BfBytes<M>, UL0>(p);
 }
 // bit-packed rows of W dwords; CARRY: the row's last dword rides through the survivor queue
 template <int W, bool CARRY, bool UL0>
-__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_SCAN_SGPRS VAQ_BF_VGPR_CAP void scan_bits_bf_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_MAX_THREADS) VAQ_BF_SGPRS VAQ_BF_VGPR_CAP void scan_bits_bf_kernel(ScanParams p) {
   scan_bf_body<BfBits<W, CARRY>, UL0>(p);
 }
 
