@@ -288,10 +288,12 @@ template <int M> struct BfBytes {
     it.load(codes, (int64_t)(base_row / ROWS) + lane);
   }
   __device__ __forceinline__ float lut4(const uint32_t c4, const int g) const {
-    float dism = lds_lut<0>((g * 4 + 0) * 1024, c4);
-    dism = dism + lds_lut<1>((g * 4 + 1) * 1024, c4);
-    dism = dism + lds_lut<2>((g * 4 + 2) * 1024, c4);
-    dism = dism + lds_lut<3>((g * 4 + 3) * 1024, c4);
+    // (the four entries first: one LDS round trip, not two)
+    const float l0 = lds_lut<0>((g * 4 + 0) * 1024, c4), l1 = lds_lut<1>((g * 4 + 1) * 1024, c4);
+    const float l2 = lds_lut<2>((g * 4 + 2) * 1024, c4), l3 = lds_lut<3>((g * 4 + 3) * 1024, c4);
+    float dism = l0 + l1;
+    dism = dism + l2;
+    dism = dism + l3;
     return dism;
   }
   template <bool UL0> __device__ __forceinline__ float first_two(const Item &it, const int r, const float l0) const {
@@ -1106,6 +1108,10 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       const int t_next = take_ticket();
       STAT_ADD(ST_BUCKETS_TESTED, 1);
       const float lbv = bits_to_float(key & ~idx_mask);
+      // steps [st_lo, st_lo + n_int) of the unit have all their rows inside [pos, be)
+      const int st_lo = pos > base0 ? 1 : 0;
+      const int st_hi = be < base0 + nst * WSTEP ? nst - 1 : nst;
+      const int n_int = st_hi > st_lo ? st_hi - st_lo : 0;
       // buckets come in ascending order of their bound and thresholds only fall: nothing
       // from here on can hold an admissible row
       if (!p.no_skip && lbv > thr_d) break;
@@ -1122,7 +1128,9 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
         const int base = base0 + st * WSTEP;
         STAT_ADD(ST_STEPS, 1);
         refresh(stepno++);
-        const bool interior = base >= pos && base + WSTEP <= be;  // wave-uniform: no per-row range test
+        // wave-uniform: no per-row range test on the steps that lie inside the unit -- all but, at most, its
+        // first and its last one (st_lo, n_int: per unit, below; one subtraction and one compare per step)
+        const bool interior = (unsigned)(st - st_lo) < (unsigned)n_int;
         const int row0 = base + lane * ROWS;
         float part[ROWS];
         // a row that survived its first group: to the survivor queue (or, a one-group row, to the candidates)
@@ -1240,8 +1248,48 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
 #endif
   // wave 0 cuts a long pool to exactly the k best (ties cut by label); the waves then share the ordering
   if (wave == 0) {
-    const int n0 = (int)sel.hdr[SEL_NCAND];
+    int n0 = (int)sel.hdr[SEL_NCAND];
     PH_MARK(8);
+    // The histogram of the admitted distances already brackets the k-th best: with jb the first bin at which
+    // the running count reaches k, every one of the k best lies in a bin <= jb (k admitted rows -- rows of the
+    // database, each counted once -- lie in bins <= jb, so a row of a later bin has k rows strictly below it;
+    // rows the pool dropped on the way were above k kept ones and change nothing).  Keeping those bins' rows
+    // -- one pass, no bisection -- leaves the k best and the few rows sharing the last bin with them, which
+    // the ranking below orders; it was the bisection of pool_compact, run by this wave alone while the
+    // others wait, that made the final cut 8 % of a C2 workgroup's life.
+    const float hscale = bits_to_float(sel.hdr[BF_HDR_SCALE]);
+    if (n0 > k && hscale != 0.0f) {
+      int inc = (int)hist[lane];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(inc, o);
+        if (lane >= o) inc += x;
+      }
+      const unsigned long long reach = __ballot(inc >= k);
+      const int jb = reach != 0ull ? __builtin_ctzll(reach) : BF_HIST_BINS - 1;
+      if (jb < BF_HIST_BINS - 1) {  // (the last bin also holds everything beyond H: nothing to drop)
+        int w = 0;
+        for (int base = 0; base < n0; base += 64) {
+          const int i = base + lane;
+          const float di = i < n0 ? sel.d[i] : INFINITY;
+          const int ii = i < n0 ? sel.id[i] : ID_SENTINEL;
+          const unsigned b = (unsigned)(di * hscale);  // the bin it was counted in (flush)
+          const bool keep = i < n0 && (b < BF_HIST_BINS - 1 ? b : BF_HIST_BINS - 1) <= (unsigned)jb;
+          const unsigned long long m = __ballot(keep);
+          wave_lds_sync();
+          if (keep) {
+            const int pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            sel.d[pos] = di;
+            sel.id[pos] = ii;
+          }
+          w += __popcll(m);
+          wave_lds_sync();
+        }
+        n0 = w;
+        if (lane == 0) sel.hdr[SEL_NCAND] = (unsigned)n0;
+        wave_lds_sync();
+      }
+    }
     // (up to BF_RANK_SORT_MAX rows are ranked as they are, the k first written: no cut needed)
     if (n0 > k && n0 > BF_RANK_SORT_MAX) pool_compact(sel, n0, k, cap, cap, lane);  // (leaves the new count in the header)
     PH_MARK(9);
@@ -1269,18 +1317,20 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
       // The other rows are broadcast reads of LDS, independent of each other: no chain of
       // dependent compare-exchange stages as in a sorting network (28 for 128 rows).  Wave w takes
       // rows [64 w, 64 w + 64), ...
+      // (the keys packed once, in the waves' buffers -- idle by now: the counting loop is then one 8-byte
+      //  broadcast read, one 64-bit compare and one add per row)
+      unsigned long long *pk = reinterpret_cast<unsigned long long *>(kuns);
+      for (int i = tid; i < n; i += nthreads) pk[i] = ((unsigned long long)float_to_bits(sel.d[i]) << 32) | (unsigned)sel.id[i];
+      __syncthreads();
       for (int base = wave * 64; base < n; base += nwaves * 64) {
         const int i = base + lane;
         const bool valid = i < n;
-        const float di = valid ? sel.d[i] : INFINITY;
-        const int ii = valid ? sel.id[i] : ID_SENTINEL;
-        const unsigned long long ki = ((unsigned long long)float_to_bits(di) << 32) | (unsigned)ii;
+        const unsigned long long ki = valid ? pk[i] : ~0ull;
+        const float di = bits_to_float((unsigned)(ki >> 32));
+        const int ii = valid ? (int)(unsigned)ki : ID_SENTINEL;
         int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < n; j++) {
-          const unsigned long long kj = ((unsigned long long)float_to_bits(sel.d[j]) << 32) | (unsigned)sel.id[j];
-          rank += kj < ki ? 1 : 0;
-        }
+#pragma unroll 8
+        for (int j = 0; j < n; j++) rank += pk[j] < ki ? 1 : 0;
         if (valid && rank < k) emit(rank, di, ii);
         if (bm_handed && valid && rank == k - 1) atomicMin(&p.g_thr[qi], float_to_bits(di));
       }
