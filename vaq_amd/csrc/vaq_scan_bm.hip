@@ -436,7 +436,22 @@ __host__ __device__ inline size_t bm_lds_bytes(int M, int qb, int nwaves) {
   return (size_t)M * 256 * qb * 4 + (size_t)nwaves * (BM_QCAP * 4 * (3 + qcw) + BM_CB_CAP * 12);
 }
 
+// The QB entries (one per query of the group) of code byte B in table T of the interleaved tables at LDS
+// offset 0: byte_shl puts the byte's offset (16 or 8 bytes per code) in one instruction, the table's
+// offset is the load's immediate (vaq_scan.h, lds_lut).
+template <int QB, int B, typename VT> __device__ __forceinline__ VT lds_lut_vec(const unsigned table, const unsigned c) {
+  typedef __attribute__((address_space(3))) const VT lds_cvt;
+  constexpr int SH = QB == 4 ? 4 : 3;
+  return *reinterpret_cast<lds_cvt *>((uintptr_t)(byte_shl<B, SH>(c) + table * (256u * QB * 4u)));
+}
+// one query's entry: i4 = 4 * (slot of the query in the group), per lane
+template <int QB, int B> __device__ __forceinline__ float lds_lut_q(const unsigned table, const unsigned c, const unsigned i4) {
+  constexpr int SH = QB == 4 ? 4 : 3;
+  return *reinterpret_cast<lds_cfloat *>((uintptr_t)(byte_shl<B, SH>(c) + i4 + table * (256u * QB * 4u)));
+}
+
 constexpr int BM_MAX_RUNS = 256;  // second codes of a bucket (bucket_t == 0: all 256)
+constexpr int BM_TABLES_BYTES = 8192;  // the scan kernel's per-workgroup tables, after bm_lds_bytes()
 
 // SUB: the rows of a bucket are ordered by the second code (BmParams::sub_start): a RUN of rows shares
 // its first two table terms, so l0 + l1 is one value per (run, query) -- the first early-abandon test
@@ -450,15 +465,24 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
   constexpr int WPR = M / 4;
   constexpr int QCW = (M <= 16) ? WPR - 1 : 0;
   constexpr int WSTEP = 64 * ROWS;
+  // No static LDS: the lookup tables sit at LDS offset 0 and are addressed by integer (lds_lut_vec below:
+  // a table's offset goes into the instruction's immediate field); the small per-workgroup tables follow the
+  // waves' buffers (BM_TABLES_BYTES, bm_tables_*).
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_ioff[BF_MAX_BUCKETS / BM_XCDS + 2];
-  __shared__ int s_ticket;
-  __shared__ unsigned s_thr[QB];
-  __shared__ int s_q[QB];
-  // runs of the item's bucket (SUB): rows, prefix of the wave steps of the runs in reach, l0 + l1 per query
-  __shared__ int s_run_s[SUB ? BM_MAX_RUNS : 1], s_run_e[SUB ? BM_MAX_RUNS : 1], s_cum[SUB ? BM_MAX_RUNS + 1 : 1];
-  __shared__ float s_p01[SUB ? BM_MAX_RUNS * QB : 1];
   const int tid = threadIdx.x, nthreads = blockDim.x;
+  unsigned char *tb = smem + bm_lds_bytes(M, QB, (int)(blockDim.x >> 6));
+  int *s_ioff = reinterpret_cast<int *>(tb);                       // [BF_MAX_BUCKETS / BM_XCDS + 2]
+  int &s_ticket = *reinterpret_cast<int *>(tb + 528);
+  unsigned *s_thr = reinterpret_cast<unsigned *>(tb + 544);        // [QB]
+  int *s_q = reinterpret_cast<int *>(tb + 560);                    // [QB]
+  // runs of the item's bucket (SUB): rows, prefix of the wave steps of the runs in reach, l0 + l1 per query
+  int *s_run_s = reinterpret_cast<int *>(tb + 576);                // [BM_MAX_RUNS]
+  int *s_run_e = s_run_s + BM_MAX_RUNS;                            // [BM_MAX_RUNS]
+  int *s_cum = s_run_e + BM_MAX_RUNS;                              // [BM_MAX_RUNS + 1]
+  float *s_p01 = reinterpret_cast<float *>(tb + 576 + 4 * (3 * BM_MAX_RUNS + 4));  // [BM_MAX_RUNS * QB]
+  static_assert(576 + 4 * (3 * BM_MAX_RUNS + 4) + 4 * BM_MAX_RUNS * QB <= BM_TABLES_BYTES, "the tables' block");
+  static_assert((BF_MAX_BUCKETS / BM_XCDS + 2) * 4 <= 528, "s_ioff");
+  lds_base_is_zero(smem);
   // (the wave number through readfirstlane: the compiler then keeps everything derived from it -- step
   //  numbers, run cursors, row ranges -- in scalar registers instead of comparing vectors under EXEC masks)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = nthreads >> 6;
@@ -697,6 +721,7 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         const int row = q_row[slot];
         float acc = q_part[slot];
         const int i = q_i[slot];
+        const unsigned i4 = (unsigned)i * 4u;
         const float tl = pick_thr(i);
         bool alive = ok;
         uint32_t cw[QCW > 0 ? QCW : 1];
@@ -706,10 +731,11 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         for (int gq = 1; gq < WPR; gq++) {
           const uint32_t c4 = QCW > 0 ? cw[gq - 1] : codes[(int64_t)row * WPR + gq];
           if (alive) {
-            float dism = lut[(size_t)((gq * 4 + 0) * 256 + (c4 & 0xffu)) * QB + i];
-            dism = dism + lut[(size_t)((gq * 4 + 1) * 256 + ((c4 >> 8) & 0xffu)) * QB + i];
-            dism = dism + lut[(size_t)((gq * 4 + 2) * 256 + ((c4 >> 16) & 0xffu)) * QB + i];
-            dism = dism + lut[(size_t)((gq * 4 + 3) * 256 + (c4 >> 24)) * QB + i];
+            const float e0 = lds_lut_q<QB, 0>(gq * 4 + 0, c4, i4), e1 = lds_lut_q<QB, 1>(gq * 4 + 1, c4, i4);
+            const float e2 = lds_lut_q<QB, 2>(gq * 4 + 2, c4, i4), e3 = lds_lut_q<QB, 3>(gq * 4 + 3, c4, i4);
+            float dism = e0 + e1;
+            dism = dism + e2;
+            dism = dism + e3;
             acc = acc + dism;  // dist += dism
             alive = acc <= tl;
           }
@@ -749,47 +775,42 @@ __global__ __launch_bounds__(BM_MAX_THREADS) void scan_bm_kernel(BmParams p) {
         for (int r = 0; r < ROWS; r++) {
           const int row = base + lane * ROWS + r;
           const uint32_t c0 = cur.word(r, 0);
-          const bool in_range = interior || (row >= rs && row < re);
           float part[QB];
           bool alive[QB];
-          bool any = false;
+          // The first group's sum in a straight line -- SUB: dism (= l0 + l1, the run's) += l2; dism += l3;
+          // otherwise dism = l0; dism += l1; dism += l2; dism += l3 -- and one test per query.  (A test after
+          // l1 saved nothing: some lane of nearly every step passes it, as in the best-first form.)  On the
+          // steps at a row range's edges the rows outside it get +inf in place of their sums: the
+          // wave-uniform branch keeps the range tests off the interior steps, and the masks below are the
+          // compares' own results.
+          const VT v2 = lds_lut_vec<QB, 2, VT>(2, c0);
+          const VT v3 = lds_lut_vec<QB, 3, VT>(3, c0);
+          VT pv;  // (element-wise vector adds: the packed fp32 add does two of them per instruction)
           if (SUB) {
-            // dism (= l0 + l1, the run's) += l2; dism += l3 -> the first group's sum
-            const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
-            const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
-            VT pv;  // (element-wise vector adds: the packed fp32 add does two of them per instruction)
 #pragma unroll
             for (int i = 0; i < QB; i++) pv[i] = p01[i];
-            pv = pv + v2;
-            pv = pv + v3;
-#pragma unroll
-            for (int i = 0; i < QB; i++) {
-              part[i] = pv[i];
-              alive[i] = in_range && part[i] <= thr[i];
-              any = any || alive[i];
-            }
-            if (__ballot(any) == 0ull) continue;
           } else {
-            // A: dism = l0; dism += l1
-            const VT v1 = *reinterpret_cast<const VT *>(&lut[(size_t)(256 + ((c0 >> 8) & 0xffu)) * QB]);
+            const VT v1 = lds_lut_vec<QB, 1, VT>(1, c0);
 #pragma unroll
-            for (int i = 0; i < QB; i++) {
-              part[i] = l0[i] + v1[i];
-              alive[i] = in_range && part[i] <= thr[i];
-              any = any || alive[i];
-            }
-            if (__ballot(any) == 0ull) continue;
-            if (any) {  // A2: dism += l2; dism += l3 -> the first group's sum
-              const VT v2 = *reinterpret_cast<const VT *>(&lut[(size_t)(512 + ((c0 >> 16) & 0xffu)) * QB]);
-              const VT v3 = *reinterpret_cast<const VT *>(&lut[(size_t)(768 + (c0 >> 24)) * QB]);
+            for (int i = 0; i < QB; i++) pv[i] = l0[i];
+            pv = pv + v1;
+          }
+          pv = pv + v2;
+          pv = pv + v3;
+          if (!interior) {
+            if (row < rs || row >= re) {
 #pragma unroll
-              for (int i = 0; i < QB; i++) {
-                part[i] = part[i] + v2[i];
-                part[i] = part[i] + v3[i];
-                alive[i] = alive[i] && part[i] <= thr[i];
-              }
+              for (int i = 0; i < QB; i++) pv[i] = INFINITY;
             }
           }
+          unsigned long long any = 0ull;
+#pragma unroll
+          for (int i = 0; i < QB; i++) {
+            part[i] = pv[i];
+            alive[i] = part[i] <= thr[i];
+            any |= __ballot(alive[i]);
+          }
+          if (any == 0ull) continue;
 #pragma unroll
           for (int i = 0; i < QB; i++) {
             const unsigned long long m = __ballot(alive[i]);
@@ -1055,10 +1076,10 @@ static hipError_t launch_bm_kernel(K kernel, const BmParams &p, size_t lds, int 
 hipError_t launch_scan_bm(const BmParams &p, int n_cu, hipStream_t st) {
   if (p.nq <= 0) return hipSuccess;
   if (p.nwaves < 1 || p.nwaves > 16) return hipErrorInvalidValue;
-  const size_t lds = bm_lds_bytes(p.M, p.qb, p.nwaves);
-  if (lds + 8192 > 160 * 1024) return hipErrorInvalidValue;  // (+ the static tables)
+  const size_t lds = bm_lds_bytes(p.M, p.qb, p.nwaves) + BM_TABLES_BYTES;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   // persistent workgroups: as many as are resident at once, a multiple of the XCD count
-  int per_cu = (int)((160 * 1024) / (lds + 8192));
+  int per_cu = (int)((160 * 1024) / lds);
   const int by_waves = 32 / p.nwaves;
   per_cu = per_cu < by_waves ? per_cu : by_waves;
   per_cu = per_cu < 1 ? 1 : per_cu;
