@@ -239,7 +239,6 @@ constexpr int SCAN_MAX_THREADS = SCAN_MAX_WAVES * 64;
 // A CU admits waves by SGPR allocation too: above 80 SGPRs only 6-7 waves fit a
 // SIMD instead of 8 (MI355X_MICROARCH.md, "Residency").  The scan kernels are
 // latency-bound, so cap them and let the compiler keep the overflow in VGPR lanes.
-// (The best-first kernels run seven waves per SIMD by their LDS anyway and take 96: VAQ_BF_SGPRS.)
 #ifndef VAQ_SCAN_SGPR_CAP
 #define VAQ_SCAN_SGPR_CAP 80
 #endif

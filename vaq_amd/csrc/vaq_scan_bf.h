@@ -67,7 +67,7 @@ constexpr int BF_QCAP = 128;                    // survivor queue: at most 63 le
 constexpr int BF_MAX_BUCKETS = 1024;
 constexpr int VAQ_BF_MAX_SUBS = 128;  // VAQHIP_MAX_SUBSPACES
 #ifndef VAQ_BF_ROUND
-#define VAQ_BF_ROUND 256
+#define VAQ_BF_ROUND 128  // (256 measures the same at C2 / C3 and costs 1 KB of LDS: with 128 an eighth C2 workgroup fits a CU)
 #endif
 constexpr int BF_ROUND_BUCKETS = VAQ_BF_ROUND;  // buckets one round orders and scans
 constexpr int BF_BOOT_STEPS = VAQ_BF_BOOT;      // wave steps each wave samples to bootstrap the threshold (0 = off)
@@ -80,12 +80,15 @@ __host__ __device__ inline int bf_pow2(int n) {
 }
 // slots of the k-min pool (below): ScanParams::bf_pool, chosen by the planner between these two so
 // that the pool never costs a resident workgroup (C2, 4 waves: 23 408 B of LDS with 512 slots is
-// 6 workgroups per CU and 1.02 ms, 22 896 B with 448 is 7 and 0.94 ms)
+// 6 workgroups per CU and 1.02 ms, 22 896 B with 448 is 7 and 0.94 ms).  Round 3: a full pool first drops
+// the rows above the current threshold (one pass, flush()), and its size hardly matters any more -- C2
+// with 448 / 384 / 256 slots 0.420 / 0.426 / 0.423 ms at 7 workgroups per CU; 256 slots and 128 buckets
+// per round are 20 336 B: EIGHT workgroups per CU, 0.410 ms.
 #ifndef VAQ_BF_POOL
 #define VAQ_BF_POOL 512
 #endif
 #ifndef VAQ_BF_POOL_MIN
-#define VAQ_BF_POOL_MIN 320
+#define VAQ_BF_POOL_MIN 256
 #endif
 __host__ __device__ inline int bf_pool_min(int kp) { return 2 * kp < VAQ_BF_POOL_MIN ? VAQ_BF_POOL_MIN : 2 * kp; }
 __host__ __device__ inline int bf_pool_max(int kp) { return 2 * kp < VAQ_BF_POOL ? VAQ_BF_POOL : 2 * kp; }
@@ -132,6 +135,29 @@ __device__ __forceinline__ int pool_count_le(const float *d, const int n, const 
   return c;
 }
 
+// One wave, lock held: keeps the rows at or below (distance bits t, label tl), in place and forwards
+// (writes never pass the reads); returns their number.  Does not touch the header.
+__device__ __forceinline__ int pool_keep_le(const SelView &sel, const int cnt, const unsigned t, const int tl, const int lane) {
+  int w = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int i = base + lane;
+    const float di = i < cnt ? sel.d[i] : INFINITY;
+    const int ii = i < cnt ? sel.id[i] : ID_SENTINEL;
+    const unsigned bi = float_to_bits(di);
+    const bool keep = i < cnt && (bi < t || (bi == t && ii <= tl));
+    const unsigned long long m = __ballot(keep);
+    wave_lds_sync();
+    if (keep) {
+      const int pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      sel.d[pos] = di;
+      sel.id[pos] = ii;
+    }
+    w += __popcll(m);
+    wave_lds_sync();
+  }
+  return w;
+}
+
 // One wave, lock held, pool holds n > k rows.  Keeps every row at or below the k-th smallest
 // distance (>= k rows; more only when rows tie at that distance) and lowers the threshold to
 // (that distance, INT_MAX).  If ties leave less than `room` free slots, the tie is cut exactly:
@@ -164,27 +190,7 @@ __device__ __forceinline__ int pool_compact(const SelView &sel, const int n, con
     }
   }
   const unsigned t = lo;
-  // in-place, forwards: writes never pass the reads.  Keeps (distance bits, label) <= (t, tl).
-  auto keep_le = [&](const int cnt, const int tl) {
-    int w = 0;
-    for (int base = 0; base < cnt; base += 64) {
-      const int i = base + lane;
-      const float di = i < cnt ? sel.d[i] : INFINITY;
-      const int ii = i < cnt ? sel.id[i] : ID_SENTINEL;
-      const unsigned bi = float_to_bits(di);
-      const bool keep = i < cnt && (bi < t || (bi == t && ii <= tl));
-      const unsigned long long m = __ballot(keep);
-      wave_lds_sync();
-      if (keep) {
-        const int pos = w + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        sel.d[pos] = di;
-        sel.id[pos] = ii;
-      }
-      w += __popcll(m);
-      wave_lds_sync();
-    }
-    return w;
-  };
+  auto keep_le = [&](const int cnt, const int tl) { return pool_keep_le(sel, cnt, t, tl, lane); };
   int w = keep_le(n, INT_MAX);
   const float td = bits_to_float(t);
   int ti = INT_MAX;
@@ -713,6 +719,16 @@ __device__ __forceinline__ void scan_bf_body(const ScanParams &p) {
     unsigned long long m = __ballot(pass);
     if (m != 0ull) {
       int cnt = (int)sel.hdr[SEL_NCAND];
+      if (cnt + __popcll(m) > cap) {
+        // The pool is full.  The threshold has moved down since most of its rows came in (the histogram
+        // lowers it batch by batch): the rows above it are out of the k best whatever follows, and dropping
+        // them is ONE pass.  Only if that frees too little is the k-th best found exactly, by bisection
+        // (pool_compact: ~8 k cycles with the lock held -- a 384-slot pool cost 3 % of the C2 kernel, a
+        // 256-slot one 9 %, before this pass).
+        cnt = pool_keep_le(sel, cnt, float_to_bits(td), ti, lane);
+        if (lane == 0) sel.hdr[SEL_NCAND] = (unsigned)cnt;
+        wave_lds_sync();
+      }
       if (cnt + __popcll(m) > cap) {
         STAT_T0(t_fo);
         STAT_ADD(ST_FOLDS, 1);

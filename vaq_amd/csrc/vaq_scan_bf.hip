@@ -4,19 +4,16 @@
 namespace vaq {
 
 // UL0: every row of a bucket shares its first term (bucket key = the whole first code)
-// (72 VGPRs: seven waves per SIMD, what seven 4-wave workgroups per CU need)
-#ifndef VAQ_BF_VGPRS
-#define VAQ_BF_VGPRS 72  // (informative: waves_per_eu(7, 8) below is what enforces it)
-#endif
+// Residency: eight 4-wave workgroups per CU -- 64 VGPRs (waves_per_eu below), 80 SGPRs (up to 80 a CU
+// admits min(8, 800 / (ceil(sgpr / 16) * 16 + 16)) = 8 blocks of 256 threads, MI355X_MICROARCH.md
+// "Residency"; 96 would keep ~400 values fewer in VGPR lanes but stop at seven: C2 0.420 ms at seven,
+// 0.410 at eight) and 20 336 B of LDS at C2 (vaq_scan_bf.h, VAQ_BF_POOL_MIN).
 #ifndef VAQ_BF_WAVES_PER_SIMD
-#define VAQ_BF_WAVES_PER_SIMD 7
+#define VAQ_BF_WAVES_PER_SIMD 8
 #endif
 #define VAQ_BF_VGPR_CAP __attribute__((amdgpu_waves_per_eu(VAQ_BF_WAVES_PER_SIMD, 8)))
-// SGPRs: up to 96 a CU still admits seven 256-thread workgroups (min(8, 800 / (ceil(sgpr / 16) * 16 + 16)),
-// MI355X_MICROARCH.md "Residency") -- as many as the LDS allows here; at 80 the compiler kept ~400 values
-// in VGPR lanes (v_readlane / v_writelane in the scan loop): C2 0.541 -> 0.535 ms, C3 0.93 -> 0.92
 #ifndef VAQ_BF_SGPR_CAP
-#define VAQ_BF_SGPR_CAP 96
+#define VAQ_BF_SGPR_CAP 80
 #endif
 #define VAQ_BF_SGPRS __attribute__((amdgpu_num_sgpr(VAQ_BF_SGPR_CAP)))
 template <int M, bool UL0>

@@ -62,7 +62,7 @@ struct DevBuf {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;       // per CU on gfx950
 #ifndef VAQ_BF_WAVES_PER_SIMD
-#define VAQ_BF_WAVES_PER_SIMD 7
+#define VAQ_BF_WAVES_PER_SIMD 8
 #endif
 constexpr int BF_WAVES_PER_CU = 4 * VAQ_BF_WAVES_PER_SIMD;  // what the best-first kernels' register budget admits
 constexpr size_t LDS_GRANULE = 1280;           // allocation unit assumed when counting resident workgroups
