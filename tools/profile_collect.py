@@ -40,7 +40,9 @@ waves = c["SQ_WAVES"]
 bound = {"c2": {
     "kernel": C2,
     "bound": "instruction issue + latency of the per-workgroup phases (cache-resident, bucket-pruned scan: no HBM "
-             "roofline applies; VALUs about half busy, LDS pipe a third, 5.6 of 7 resident waves per SIMD on average)",
+             "roofline applies; VALU busy %.2f, %.1f of 8 resident waves per SIMD on average, waves parked %.2f of "
+             "their life)" % (c["SQ_ACTIVE_INST_VALU"] * 4 / (n_simd * cycles), c["SQ_WAVE_CYCLES"] * 4 / (n_simd * cycles),
+                              c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]),
     "source": "profiles/r03_default_pmc_scan.txt (rocprofv3 --pmc passes of `python3 bench.py --steps 20 "
               "--warmup 5`, tools/profile_default.sh + tools/profile_collect.py)",
     "kernel_cycles": round(cycles),
@@ -60,7 +62,8 @@ bound = {"c2": {
             "1.47 ms) 12.6 k VALU + 10.7 k SALU per wave, VALU busy 0.56, wait share 0.56, 5.3 waves per SIMD; round 2 "
             "before the prefetch fix (1.00 ms) 6.5 k + 6.4 k, VALU busy 0.42, wait share 0.56, 3.5 waves per SIMD; with "
             "the prefetch fix but before expensive queries were dispatched first (0.72 ms) VALU busy 0.42, 4.2 waves "
-            "per SIMD",
+            "per SIMD; end of round 2 / start of round 3 (0.534 ms, 7 workgroups per CU) 4.9 k VALU + 5.5 k SALU + 1.0 k "
+            "LDS per wave, VALU busy 0.60, 5.8 waves per SIMD",
 }}
 BM = "scan_bm_kernel<16, 4, true>"
 if BM in vals:
@@ -70,8 +73,10 @@ if BM in vals:
     bound["c5_bm"] = {
         "kernel": BM, "rows": 1000000000, "queries": 10000,
         "what": "the bucket-major rounds of the 1B x 16 B, 10 k-query step (scale_base): sums over the %d launches of a step" % per_step,
-        "bound": "VALU issue: every row a query group streams costs the same instructions whether one or all four of its "
-                 "queries want the run; rows come from the XCD's L2 (hit rate below), HBM is far from its limit",
+        "bound": "the memory side: a bucket of 1B rows is four times an XCD's L2, so most groups of a bucket take its rows "
+                 "from the Infinity Cache / HBM (L2 hit rate below); memory_side_bytes_per_step over the step's kernel time "
+                 "(~66 ms: profiles/r03_default_kernel_stats.csv) is ~6.6 TB/s, the fabric's ceiling.  Instruction issue no "
+                 "longer binds (valu_busy_frac; it did before the last kernel changes: 0.69)",
         "kernel_cycles_per_step": round(cyc),
         "valu_busy_frac": round(b["SQ_ACTIVE_INST_VALU"] * per_step * 4 / (n_simd * cyc), 3),
         "valu_insts_per_wave_step": round(b["SQ_INSTS_VALU"] / b["SQ_INSTS_VMEM_RD"], 1),
