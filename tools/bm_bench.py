@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--units", default="", help="comma-separated bm_units values to time (instead of the default shape)")
     ap.add_argument("--rounds", default="", help="comma-separated bm_boot:bm_round pairs to time")
     ap.add_argument("--bucket-bits", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0, help="bm_waves of the default shape (0 = library default)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -71,7 +72,7 @@ def main():
         r, l0, d0 = timed("one workgroup per query (bucket_major=0)", bucket_major=0)
         recs.append(r)
         ref = (l0, d0)
-    shapes = [dict(bucket_major=2)]
+    shapes = [dict(bucket_major=2, bm_waves=a.waves)]
     if a.units:
         shapes = [dict(bucket_major=2, bm_boot=0, bm_units=int(u)) for u in a.units.split(",")]
     if a.rounds:  # "boot:round" pairs, e.g. 1:6,1:0,0:6

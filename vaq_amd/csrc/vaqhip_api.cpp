@@ -382,6 +382,19 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
         pl->bm = true;
         pl->bm_qb = ix->opt_bm_qb > 0 ? ix->opt_bm_qb : BM_QB;
         pl->bm_nwaves = ix->opt_bm_nwaves > 0 ? ix->opt_bm_nwaves : BM_NWAVES;
+        if (ix->opt_bm_nwaves <= 0) {
+          // 16 or 8 waves per workgroup: whichever keeps more waves resident on a CU, and on a tie the
+          // smaller workgroups (more items in flight, shorter waits at an item's barriers).  8-byte rows:
+          // 16 waves need 90 KB (one workgroup), 8 waves 65 KB (two): C4 7.9 -> 6.8 ms; 16-byte rows have
+          // room for one workgroup either way, and 16 waves are 66 ms at 1B rows where 8 are 92.
+          int best_res = 0;
+          for (int nw : {16, 8}) {
+            const size_t lds = vaq::scan_bm_lds_bytes(ix->M, pl->bm_qb, nw) + 8192;
+            if (lds > LDS_LIMIT) continue;
+            const int res = std::min<int>(32, nw * (int)(LDS_LIMIT / lds));
+            if (res >= best_res) { best_res = res; pl->bm_nwaves = nw; }
+          }
+        }
         pl->bm_cap = ix->opt_bm_cap > 0 ? ix->opt_bm_cap : BM_CAND_CAP;
         while (vaq::scan_bm_lds_bytes(ix->M, pl->bm_qb, pl->bm_nwaves) + 8192 > LDS_LIMIT && pl->bm_nwaves > 4) pl->bm_nwaves >>= 1;
         // pass A: about one average bucket per query (a work unit = 64 wave steps)
