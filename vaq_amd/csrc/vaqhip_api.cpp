@@ -79,6 +79,7 @@ constexpr int64_t MIN_SLICE_ROWS = 16384;      // do not cut slices finer than t
 // rule below, which no default selects.
 // (launch_cost_order pays from about one residency of workgroups on: 7 per CU)
 constexpr int COST_ORDER_MIN_QUERIES = 1024;
+constexpr double BM_QB2_MAX_BYTES = 4.5e9;  // bucket-major rounds, 16-byte rows: two queries per group up to this many code bytes
 constexpr int DEFER_MIN_QUERIES = 4096, DEFER_UNITS = 96, DEFER_SLICES = 2, DEFER_CAP = 2048;
 constexpr int64_t BUCKET_MIN_ROWS = 900;       // average rows per bucket the bucketed order aims for
 constexpr int64_t BUCKET_MIN_ROWS_10 = 1900;   // ... before it takes a tenth key bit
@@ -381,6 +382,11 @@ int make_plan(const vaqhip_index *ix, int nq, int k, Plan *pl) {
       if (bm && s == 1) {
         pl->bm = true;
         pl->bm_qb = ix->opt_bm_qb > 0 ? ix->opt_bm_qb : BM_QB;
+        // 16-byte rows: four queries' tables are 64 KB, one 16-wave workgroup per CU.  Two queries per group
+        // in 8-wave workgroups are two workgroups per CU at twice the passes over a bucket's rows -- that
+        // pays while those passes come out of L2, i.e. on shards up to about 4 GB of codes (10 k queries:
+        // 62.5M / 125M / 250M rows 13.2 -> 12.2 / 16.6 -> 15.6 / 23.8 -> 23.3 ms; 500M 37.7 -> 39.0, 1B 65.6 -> 82.1)
+        if (ix->opt_bm_qb <= 0 && ix->M == 16 && (double)N * 16.0 <= BM_QB2_MAX_BYTES) pl->bm_qb = 2;
         pl->bm_nwaves = ix->opt_bm_nwaves > 0 ? ix->opt_bm_nwaves : BM_NWAVES;
         if (ix->opt_bm_nwaves <= 0) {
           // 16 or 8 waves per workgroup: whichever keeps more waves resident on a CU, and on a tie the
